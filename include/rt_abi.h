@@ -1,0 +1,299 @@
+/*
+ * rt_abi.h -- C ABI of the MI355X path-tracing core (librt_amd.so).
+ *
+ * This is the drop-in boundary for the per-pixel path-tracing hot path of
+ * calvin-godfrey/RustRaytracer.  The reference has no FFI seam of its own
+ * (SURVEY.md section 8b): its render driver calls
+ *     get_integrator(IntType, Camera, Samplers)   src/integrator.rs:55-87
+ *     Integrator::render(&mut grid, px, py)       src/integrator.rs:336-348
+ * once per pixel from src/render.rs:46-47,85 and reads the scene from the
+ * process-global `Objects` (src/geometry.rs:13-55).  The replacement is called
+ * once per image instead: a Rust maintainer adds `render::gpu_tile` beside
+ * `render::tile_multithread` (src/render.rs:13), flattens `get_objects()` into
+ * the POD arrays below, calls rt_render() and hands the returned sums to
+ * `util::draw_picture` (src/util.rs:387-398).  INTEGRATION.md shows that stub.
+ *
+ * Every struct here is plain old data with fixed-width fields; every function
+ * returns an int status (RT_OK or a negative rt_status) and never unwinds.
+ *
+ * Numerical contract (part of the ABI, shared with the CPU oracle):
+ *   - all arithmetic of the parity mode is IEEE binary64 without FMA
+ *     contraction, in the reference's expression order;
+ *   - elementary functions are the ones in rt_detmath.h;
+ *   - random numbers come from the counter generator specified at rt_rng_*
+ *     below, drawn in the order of SURVEY.md section 3.3;
+ *   - exact-t ties between two primitives are won by the larger prim index
+ *     (the reference's own winner is run-to-run random, hittable.rs:604-616,
+ *     645-652).
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+/* ---------------------------------------------------------------- status */
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARG = -1, /* null pointer, out-of-range index, bad enum     */
+    RT_ERR_NO_DEVICE = -2,   /* no usable HIP device / device id out of range  */
+    RT_ERR_HIP = -3,         /* a HIP runtime call failed (see rt_last_error)  */
+    RT_ERR_UNSUPPORTED = -4, /* valid but outside the hot-path scope           */
+    RT_ERR_STATE = -5,       /* call order violated (e.g. render before commit)*/
+    RT_ERR_OOM = -6          /* host or device allocation failed               */
+} rt_status;
+
+/* ------------------------------------------------------------- constants */
+/* src/consts.rs:14-20 (BxDF flag bits) -- values are part of the contract.   */
+#define RT_BSDF_REFLECTION 1u
+#define RT_BSDF_TRANSMISSION 2u
+#define RT_BSDF_DIFFUSE 4u
+#define RT_BSDF_GLOSSY 8u
+#define RT_BSDF_SPECULAR 16u
+#define RT_BSDF_ALL 31u
+/* src/consts.rs:7,30-32 */
+#define RT_MAX_DEPTH 25u
+#define RT_INFINITY 1e308
+#define RT_PI 3.14159265358979 /* truncated on purpose: src/consts.rs:31 */
+#define RT_SMALL 0.001
+
+/* --------------------------------------------------------------- scene  */
+/* Affine 3x4 transform, row-major: p' = M[0..2][0..2]*p + M[.][3].
+ * Mirrors the `Projective3<f64>` carried by transformed rects
+ * (src/primitive.rs:32,43,54).  `inv` is the inverse the reference recomputes
+ * on every test through Ray::transform (src/geometry.rs:231-235).            */
+typedef struct rt_xform {
+    double fwd[12];
+    double inv[12];
+} rt_xform;
+
+/* src/primitive.rs:10-61.  FlipFace{obj} is the `flip` bit on the inner
+ * primitive (only ever wraps rects in the reference's presets).              */
+typedef enum rt_prim_kind {
+    RT_PRIM_SPHERE = 0,   /* v[0..2] = center, v[3] = r                        */
+    RT_PRIM_TRIANGLE = 1, /* mesh_index, tri_ind = 3*face (Mesh.ind offset)    */
+    RT_PRIM_XY_RECT = 2,  /* v = x0,y0,x1,y1,k                                 */
+    RT_PRIM_XZ_RECT = 3,  /* v = x0,z0,x1,z1,k                                 */
+    RT_PRIM_YZ_RECT = 4   /* v = y0,z0,y1,z1,k                                 */
+} rt_prim_kind;
+
+typedef struct rt_primitive {
+    uint32_t kind;        /* rt_prim_kind                                      */
+    uint32_t flip;        /* 1 = wrapped in Primitive::FlipFace                */
+    uint32_t mat_index;
+    int32_t light_index;  /* -1 = usize::MAX = not an emitter                  */
+    uint32_t mesh_index;  /* triangles only                                    */
+    uint32_t tri_ind;     /* triangles only: offset into Mesh.ind (3*face)     */
+    int32_t xform_index;  /* rects only: -1 = None                             */
+    uint32_t reserved;
+    double v[5];
+    double bbox_min[3];   /* Primitive::get_bounding_box, f64 (hittable.rs:274,
+                             primitive.rs:66-68,93-113, util.rs:493-517)       */
+    double bbox_max[3];
+} rt_primitive;
+
+/* src/hittable.rs:242-250: ith triangle = p[ind[3i]], p[ind[3i+1]], ...      */
+typedef struct rt_mesh {
+    const double* p;      /* n_p * 3                                           */
+    const double* n;      /* n_n * 3, n_n == 0 or n_p (un-normalised allowed)  */
+    const double* uv;     /* n_uv * 2, n_uv == 0 or n_p                        */
+    const uint32_t* ind;  /* n_ind, multiple of 3                              */
+    uint64_t n_p, n_n, n_uv, n_ind;
+} rt_mesh;
+
+/* src/material.rs:519-539; only the kinds the hot-path scope covers.          */
+typedef enum rt_texture_kind {
+    RT_TEX_SOLID = 0,     /* color                                             */
+    RT_TEX_CHECKERED = 1  /* odd, even texture ids + frequency                 */
+} rt_texture_kind;
+
+typedef struct rt_texture {
+    uint32_t kind;
+    uint32_t odd;         /* Checkered.odd  (material.rs:527-531)              */
+    uint32_t even;
+    uint32_t reserved;
+    double color[3];
+    double frequency;
+} rt_texture;
+
+/* src/material.rs:17-73 */
+typedef enum rt_material_kind {
+    RT_MAT_MATTE = 0,    /* tex[0]=k_d; f[0]=sigma (only sigma==0 supported)   */
+    RT_MAT_LIGHT = 1,    /* no lobes                                           */
+    RT_MAT_PLASTIC = 2,  /* tex[0]=k_d, tex[1]=k_s; f[0]=roughness             */
+    RT_MAT_GLASS = 3,    /* tex[0]=k_r, tex[1]=k_t; f[0]=u_rough f[1]=v_rough
+                            f[2]=index (only smooth supported)                 */
+    RT_MAT_METAL = 4,    /* tex[0]=eta, tex[1]=k, tex[2]=rough, tex[3]=urough,
+                            tex[4]=vrough (RT_NO_TEXTURE = usize::MAX)         */
+    RT_MAT_MIRROR = 5    /* tex[0]=color                                       */
+} rt_material_kind;
+
+#define RT_NO_TEXTURE 0xFFFFFFFFu
+
+typedef struct rt_material {
+    uint32_t kind;
+    uint32_t remap_roughness;
+    uint32_t tex[5];
+    uint32_t reserved;
+    double f[3];
+} rt_material;
+
+/* src/light.rs:59-69: only Light::Diffuse is in scope.                        */
+typedef enum rt_light_kind { RT_LIGHT_DIFFUSE = 0 } rt_light_kind;
+
+typedef struct rt_light {
+    uint32_t kind;
+    uint32_t prim_index;
+    uint32_t two_sided;
+    uint32_t reserved;
+    double color[3];
+    double area;          /* Primitive::area() at construction (light.rs:603)  */
+} rt_light;
+
+/* Flattened `Objects` (src/geometry.rs:13-21), caller-owned.                  */
+typedef struct rt_scene_desc {
+    const rt_mesh* meshes;        uint64_t n_meshes;
+    const rt_primitive* prims;    uint64_t n_prims;
+    const rt_xform* xforms;       uint64_t n_xforms;
+    const rt_material* materials; uint64_t n_materials;
+    const rt_texture* textures;   uint64_t n_textures;
+    const rt_light* lights;       uint64_t n_lights;
+} rt_scene_desc;
+
+/* The ten fields of `Camera` (src/geometry.rs:96-108), precomputed by the
+ * caller with Camera::new_motion_blur (geometry.rs:133-175).                  */
+typedef struct rt_camera {
+    double origin[3];
+    double upper_left_corner[3];
+    double horizontal_offset[3];
+    double vertical_offset[3];
+    double lens_radius;
+    double t0, t1;
+    double u[3], v[3], w[3];
+} rt_camera;
+
+/* ---------------------------------------------------------------- render */
+typedef enum rt_precision {
+    RT_PRECISION_F64 = 0  /* parity mode: bit-comparable with the oracle       */
+} rt_precision;
+
+typedef struct rt_render_cfg {
+    uint32_t width, height;   /* GLOBAL_STATE image size (main.rs:82-88)       */
+    uint32_t spp;             /* rounded up to a power of two like
+                                 sampler.rs:633-642                            */
+    uint32_t max_depth;       /* 25 in the reference (consts.rs:7)             */
+    uint64_t seed;
+    uint32_t x0, y0, x1, y1;  /* pixel window [x0,x1) x [y0,y1); 0,0,0,0 = all */
+    uint32_t tile_size;       /* 16 (consts.rs:10); 0 = 16                     */
+    uint32_t tile_rank;       /* this caller renders tiles k with              */
+    uint32_t tile_world;      /*   k % tile_world == tile_rank; 0 = 1          */
+    uint32_t precision;       /* rt_precision                                  */
+    uint32_t paths_in_flight; /* 0 = library default                           */
+    uint32_t flags;           /* RT_RENDER_* below                             */
+} rt_render_cfg;
+
+#define RT_RENDER_COUNT_TRAVERSAL 1u /* fill the node/prim test counters       */
+
+/* Counters.  rays_* are the three root closest-hit call sites of
+ * R1 integrator.rs:388, R2 integrator.rs:584 (hittable.rs:30),
+ * R3 integrator.rs:615.  They must equal the oracle's exactly.                */
+typedef struct rt_stats {
+    uint64_t paths;            /* camera samples started                       */
+    uint64_t rays_extension;   /* R1, primary included                         */
+    uint64_t rays_shadow;      /* R2                                           */
+    uint64_t rays_probe;       /* R3                                           */
+    uint64_t vertices_shaded;  /* compute_scattering calls                     */
+    uint64_t nodes_fetched;    /* BVH nodes fetched (RT_RENDER_COUNT_TRAVERSAL)*/
+    uint64_t tris_tested;
+    uint64_t others_tested;    /* sphere / rect records tested                 */
+    double kernel_ms;          /* all device work of this call (HIP events)    */
+    double trace_ms;           /* traversal kernel only (HIP events)           */
+    uint64_t trace_launches;
+    uint64_t reserved[4];
+} rt_stats;
+
+typedef struct rt_ray {
+    double origin[3];
+    double dir[3];
+    double tmin;  /* SMALL for extension rays, 0 for shadow rays (Q4)          */
+    double tmax;  /* RT_INFINITY                                               */
+} rt_ray;
+
+typedef struct rt_hit {
+    double t;       /* RT_INFINITY on miss                                     */
+    int32_t prim;   /* -1 on miss                                              */
+    uint32_t reserved;
+} rt_hit;
+
+typedef struct rt_context rt_context;
+typedef struct rt_scene rt_scene;
+
+/* One context per process and GPU.  device_ids may be NULL (device 0);
+ * n_devices must be 1 in this version (multi-GPU = one process per GPU).      */
+int rt_context_create(const int* device_ids, int n_devices, rt_context** out);
+int rt_context_destroy(rt_context* ctx);
+
+/* Scene = flattened geometry::Objects.  The library copies on set_*.          */
+int rt_scene_create(rt_context* ctx, rt_scene** out);
+int rt_scene_set_meshes(rt_scene* s, const rt_mesh* meshes, uint64_t count);
+int rt_scene_set_primitives(rt_scene* s, const rt_primitive* prims, uint64_t count);
+int rt_scene_set_transforms(rt_scene* s, const rt_xform* xforms, uint64_t count);
+int rt_scene_set_materials(rt_scene* s, const rt_material* mats, uint64_t count);
+int rt_scene_set_textures(rt_scene* s, const rt_texture* texs, uint64_t count);
+int rt_scene_set_lights(rt_scene* s, const rt_light* lights, uint64_t count);
+/* Validates indices, builds the BVH (replaces BvhNode::new,
+ * hittable.rs:637-752) and uploads everything to HBM.                         */
+int rt_scene_commit(rt_scene* s);
+int rt_scene_destroy(rt_scene* s);
+/* Sizes of the committed device layout, for roofline accounting.             */
+typedef struct rt_scene_info {
+    uint64_t n_prims, n_triangles, n_others, n_bvh_nodes, bvh_depth;
+    uint64_t node_bytes, tri_bytes, other_bytes, device_bytes_total;
+} rt_scene_info;
+int rt_scene_get_info(const rt_scene* s, rt_scene_info* out);
+
+/* Whole-image replacement for the per-pixel Integrator::render loop.
+ * rgb_sum[(y*W+x)*3+c] = sum of radiance samples, n[y*W+x] = sample count:
+ * the reference's `grid[y][x] = (r,g,b,n)` (integrator.rs:44, util.rs:208-232).
+ * Host pointers; either may be NULL to leave the film on the device.          */
+int rt_render(rt_context* ctx, rt_scene* s, const rt_camera* cam, const rt_render_cfg* cfg,
+              double* rgb_sum, uint32_t* n, rt_stats* stats);
+/* Same, writing into caller-owned DEVICE buffers (W*H*3 doubles, W*H u32),
+ * zeroed by the call, on `hip_stream` (a hipStream_t, may be NULL).           */
+int rt_render_device(rt_context* ctx, rt_scene* s, const rt_camera* cam, const rt_render_cfg* cfg,
+                     double* d_rgb_sum, uint32_t* d_n, void* hip_stream, rt_stats* stats);
+
+/* Kernel-level parity entry: closest hit of BvhNode::intersects
+ * (hittable.rs:591-634) for n host rays.                                      */
+int rt_intersect_batch(rt_context* ctx, rt_scene* s, const rt_ray* rays, uint64_t n, rt_hit* hits);
+
+/* Next-row f1: film resolve -> ACES approx -> gamma -> 8-bit
+ * (util.rs:400-408, 441-471).  rgb8 = W*H*3 bytes, host pointers.             */
+int rt_resolve_rgb8(rt_context* ctx, const double* rgb_sum, const uint32_t* n, uint32_t width,
+                    uint32_t height, uint8_t* rgb8);
+
+const char* rt_last_error(void);
+int rt_abi_version(void);
+
+/* ------------------------------------------------------------------ RNG
+ * Counter generator replacing both of the reference's unseeded streams
+ * (thread_rng, sampler.rs:317-337; StdRng::from_entropy, util.rs:32-34).
+ * One stream per (seed, pixel = py*W+px, sample); draw k is
+ *     s0  = mix(mix(seed * G + pixel) + sample * H + J)
+ *     z_k = mix(s0 + (k+1) * G)          (splitmix64 finaliser)
+ *     u_k = (z_k >> 11) * 2^-53          in [0,1)
+ * with G = 0x9E3779B97F4A7C15, H = 0xD1B54A32D192ED03, J = 0x8CB92BA72F3D8DD7.  */
+#define RT_RNG_G 0x9E3779B97F4A7C15ull
+#define RT_RNG_H 0xD1B54A32D192ED03ull
+#define RT_RNG_J 0x8CB92BA72F3D8DD7ull
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_ABI_H */

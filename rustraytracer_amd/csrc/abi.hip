@@ -1,0 +1,635 @@
+// abi.hip -- implementation of the C ABI declared in include/rt_abi.h.
+// Handles, validation, HBM residency, the per-chunk launch schedule and timing.
+// Nothing here falls back to a CPU path: without a HIP device every compute entry
+// returns RT_ERR_NO_DEVICE / RT_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "bvh_build.h"
+#include "device/kernels.hip"
+
+using namespace rtd;
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                            \
+    } while (0)
+
+// ------------------------------------------------------------------ handles
+struct rt_context {
+    int device = 0;
+    int num_cus = 256;
+    hipStream_t stream = nullptr;
+    // path-state pool
+    uint32_t capacity = 0;
+    void* pool = nullptr;
+    PathState st{};
+    uint32_t* active[2] = {nullptr, nullptr};
+    uint32_t* queue[2] = {nullptr, nullptr};
+    Ctl* ctl = nullptr;
+    DevStats* stats = nullptr;
+    uint32_t* pix_list = nullptr;
+    size_t pix_capacity = 0;
+    std::vector<hipEvent_t> events;
+};
+
+struct rt_scene {
+    rt_context* ctx = nullptr;
+    // host copies (set_* copies; commit consumes)
+    struct HostMesh {
+        std::vector<double> p, n, uv;
+        std::vector<uint32_t> ind;
+    };
+    std::vector<HostMesh> meshes;
+    std::vector<rt_primitive> prims;
+    std::vector<rt_xform> xforms;
+    std::vector<rt_material> mats;
+    std::vector<rt_texture> texs;
+    std::vector<rt_light> lights;
+    bool committed = false;
+    // device
+    std::vector<void*> allocs;
+    DevScene dev{};
+    rt_scene_info info{};
+};
+
+static int ensure_ctx_capacity(rt_context* c, uint32_t cap) {
+    if (c->capacity >= cap) return RT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->pool) {
+        HIP_TRY(hipFree(c->pool));
+        c->pool = nullptr;
+        c->capacity = 0;
+    }
+    // one slab: 27 double arrays, rng, 3 int arrays, flags, 2 active lists, 2 ray queues (3 rays per path)
+    const size_t n = cap;
+    const size_t bytes = n * (27 * 8 + 8 + 3 * 4 + 4 + 2 * 4 + 2 * 3 * 4) + 4096;
+    HIP_TRY(hipMalloc(&c->pool, bytes));
+    char* p = (char*)c->pool;
+    auto take = [&](size_t sz) {
+        char* r = p;
+        p += (sz + 255) & ~(size_t)255;
+        return (void*)r;
+    };
+    (void)take;
+    // carve without per-array padding beyond 8-byte alignment (n is a multiple of 64)
+    double** dptrs[] = {&c->st.ox, &c->st.oy, &c->st.oz, &c->st.dx, &c->st.dy, &c->st.dz, &c->st.spx, &c->st.spy, &c->st.spz,
+                        &c->st.pdx, &c->st.pdy, &c->st.pdz, &c->st.bx, &c->st.by, &c->st.bz, &c->st.lx, &c->st.ly, &c->st.lz,
+                        &c->st.ax, &c->st.ay, &c->st.az, &c->st.qx, &c->st.qy, &c->st.qz, &c->st.kx, &c->st.ky, &c->st.kz};
+    for (auto dp : dptrs) {
+        *dp = (double*)p;
+        p += n * 8;
+    }
+    c->st.rng = (uint64_t*)p; p += n * 8;
+    c->st.hit_prim = (int32_t*)p; p += n * 4;
+    c->st.sh_prim = (int32_t*)p; p += n * 4;
+    c->st.pr_prim = (int32_t*)p; p += n * 4;
+    c->st.flags = (uint32_t*)p; p += n * 4;
+    c->active[0] = (uint32_t*)p; p += n * 4;
+    c->active[1] = (uint32_t*)p; p += n * 4;
+    c->queue[0] = (uint32_t*)p; p += n * 12;
+    c->queue[1] = (uint32_t*)p; p += n * 12;
+    c->capacity = cap;
+    return RT_OK;
+}
+
+template <typename T>
+static int upload(rt_scene* s, const T* host, size_t count, const T** dev) {
+    *dev = nullptr;
+    if (count == 0) return RT_OK;
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, count * sizeof(T)));
+    s->allocs.push_back(d);
+    HIP_TRY(hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice));
+    s->info.device_bytes_total += count * sizeof(T);
+    *dev = (const T*)d;
+    return RT_OK;
+}
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_err; }
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+int rt_context_create(const int* device_ids, int n_devices, rt_context** out) {
+    if (!out) return fail(RT_ERR_INVALID_ARG, "rt_context_create: out is null");
+    *out = nullptr;
+    if (n_devices < 0 || n_devices > 1)
+        return fail(RT_ERR_UNSUPPORTED, "rt_context_create: one device per context (one process per GPU)");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device: %s", hipGetErrorString(e));
+    int dev = (device_ids && n_devices == 1) ? device_ids[0] : 0;
+    if (dev < 0 || dev >= count) return fail(RT_ERR_NO_DEVICE, "device %d out of range (%d devices)", dev, count);
+    rt_context* c = new (std::nothrow) rt_context();
+    if (!c) return fail(RT_ERR_OOM, "host allocation failed");
+    c->device = dev;
+    HIP_TRY(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc((void**)&c->ctl, sizeof(Ctl)));
+    HIP_TRY(hipMalloc((void**)&c->stats, sizeof(DevStats)));
+    *out = c;
+    return RT_OK;
+}
+
+int rt_context_destroy(rt_context* c) {
+    if (!c) return RT_OK;
+    (void)hipSetDevice(c->device);
+    for (auto ev : c->events) (void)hipEventDestroy(ev);
+    if (c->pool) (void)hipFree(c->pool);
+    if (c->ctl) (void)hipFree(c->ctl);
+    if (c->stats) (void)hipFree(c->stats);
+    if (c->pix_list) (void)hipFree(c->pix_list);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return RT_OK;
+}
+
+int rt_scene_create(rt_context* ctx, rt_scene** out) {
+    if (!ctx || !out) return fail(RT_ERR_INVALID_ARG, "rt_scene_create: null argument");
+    rt_scene* s = new (std::nothrow) rt_scene();
+    if (!s) return fail(RT_ERR_OOM, "host allocation failed");
+    s->ctx = ctx;
+    *out = s;
+    return RT_OK;
+}
+
+#define SCENE_MUTABLE(s)                                                      \
+    if (!(s)) return fail(RT_ERR_INVALID_ARG, "scene is null");               \
+    if ((s)->committed) return fail(RT_ERR_STATE, "scene is already committed")
+
+int rt_scene_set_meshes(rt_scene* s, const rt_mesh* meshes, uint64_t count) {
+    SCENE_MUTABLE(s);
+    if (count && !meshes) return fail(RT_ERR_INVALID_ARG, "meshes is null");
+    s->meshes.clear();
+    for (uint64_t i = 0; i < count; i++) {
+        const rt_mesh& m = meshes[i];
+        if (!m.p || !m.ind || m.n_p == 0 || m.n_ind % 3 != 0)
+            return fail(RT_ERR_INVALID_ARG, "mesh %llu: missing positions/indices or n_ind not a multiple of 3",
+                        (unsigned long long)i);
+        if ((m.n_n != 0 && m.n_n != m.n_p) || (m.n_uv != 0 && m.n_uv != m.n_p) || (m.n_n && !m.n) || (m.n_uv && !m.uv))
+            return fail(RT_ERR_INVALID_ARG, "mesh %llu: normals/uvs must be absent or one per position",
+                        (unsigned long long)i);
+        for (uint64_t k = 0; k < m.n_ind; k++)
+            if (m.ind[k] >= m.n_p)
+                return fail(RT_ERR_INVALID_ARG, "mesh %llu: index %u out of range", (unsigned long long)i, m.ind[k]);
+        rt_scene::HostMesh hm;
+        hm.p.assign(m.p, m.p + m.n_p * 3);
+        if (m.n_n) hm.n.assign(m.n, m.n + m.n_n * 3);
+        if (m.n_uv) hm.uv.assign(m.uv, m.uv + m.n_uv * 2);
+        hm.ind.assign(m.ind, m.ind + m.n_ind);
+        s->meshes.push_back(std::move(hm));
+    }
+    return RT_OK;
+}
+int rt_scene_set_primitives(rt_scene* s, const rt_primitive* prims, uint64_t count) {
+    SCENE_MUTABLE(s);
+    if (count && !prims) return fail(RT_ERR_INVALID_ARG, "prims is null");
+    if (count >= (1ull << 28)) return fail(RT_ERR_UNSUPPORTED, "too many primitives");
+    s->prims.assign(prims, prims + count);
+    return RT_OK;
+}
+int rt_scene_set_transforms(rt_scene* s, const rt_xform* x, uint64_t count) {
+    SCENE_MUTABLE(s);
+    if (count && !x) return fail(RT_ERR_INVALID_ARG, "xforms is null");
+    s->xforms.assign(x, x + count);
+    return RT_OK;
+}
+int rt_scene_set_materials(rt_scene* s, const rt_material* m, uint64_t count) {
+    SCENE_MUTABLE(s);
+    if (count && !m) return fail(RT_ERR_INVALID_ARG, "materials is null");
+    s->mats.assign(m, m + count);
+    return RT_OK;
+}
+int rt_scene_set_textures(rt_scene* s, const rt_texture* t, uint64_t count) {
+    SCENE_MUTABLE(s);
+    if (count && !t) return fail(RT_ERR_INVALID_ARG, "textures is null");
+    s->texs.assign(t, t + count);
+    return RT_OK;
+}
+int rt_scene_set_lights(rt_scene* s, const rt_light* l, uint64_t count) {
+    SCENE_MUTABLE(s);
+    if (count && !l) return fail(RT_ERR_INVALID_ARG, "lights is null");
+    if (count > 65535) return fail(RT_ERR_UNSUPPORTED, "more than 65535 lights");
+    s->lights.assign(l, l + count);
+    return RT_OK;
+}
+
+static int validate_scene(const rt_scene* s) {
+    for (size_t i = 0; i < s->texs.size(); i++) {
+        const rt_texture& t = s->texs[i];
+        if (t.kind == RT_TEX_CHECKERED) {
+            if (t.odd >= s->texs.size() || t.even >= s->texs.size())
+                return fail(RT_ERR_INVALID_ARG, "texture %zu: checker child out of range", i);
+        } else if (t.kind != RT_TEX_SOLID) {
+            return fail(RT_ERR_UNSUPPORTED, "texture %zu: kind %u is outside the hot-path scope", i, t.kind);
+        }
+    }
+    auto tex_ok = [&](uint32_t id) { return id < s->texs.size(); };
+    for (size_t i = 0; i < s->mats.size(); i++) {
+        const rt_material& m = s->mats[i];
+        switch (m.kind) {
+            case RT_MAT_MATTE:
+                if (!tex_ok(m.tex[0])) return fail(RT_ERR_INVALID_ARG, "material %zu: texture out of range", i);
+                if (m.f[0] != 0.0) return fail(RT_ERR_UNSUPPORTED, "material %zu: Oren-Nayar (sigma != 0) is out of scope", i);
+                break;
+            case RT_MAT_LIGHT: break;
+            case RT_MAT_PLASTIC:
+            case RT_MAT_GLASS:
+                if (!tex_ok(m.tex[0]) || !tex_ok(m.tex[1])) return fail(RT_ERR_INVALID_ARG, "material %zu: texture out of range", i);
+                if (m.kind == RT_MAT_GLASS && (m.f[0] != 0.0 || m.f[1] != 0.0))
+                    return fail(RT_ERR_UNSUPPORTED, "material %zu: rough glass (MicrofacetTransmission) is out of scope", i);
+                break;
+            case RT_MAT_METAL:
+                if (!tex_ok(m.tex[0]) || !tex_ok(m.tex[1])) return fail(RT_ERR_INVALID_ARG, "material %zu: texture out of range", i);
+                for (int k = 3; k <= 4; k++) {
+                    uint32_t id = m.tex[k] == RT_NO_TEXTURE ? m.tex[2] : m.tex[k];
+                    if (!tex_ok(id)) return fail(RT_ERR_INVALID_ARG, "material %zu: roughness texture out of range", i);
+                }
+                break;
+            case RT_MAT_MIRROR:
+                if (!tex_ok(m.tex[0])) return fail(RT_ERR_INVALID_ARG, "material %zu: texture out of range", i);
+                break;
+            default: return fail(RT_ERR_UNSUPPORTED, "material %zu: kind %u is outside the hot-path scope", i, m.kind);
+        }
+    }
+    for (size_t i = 0; i < s->prims.size(); i++) {
+        const rt_primitive& p = s->prims[i];
+        if (p.kind > RT_PRIM_YZ_RECT) return fail(RT_ERR_INVALID_ARG, "primitive %zu: bad kind %u", i, p.kind);
+        if (p.mat_index >= s->mats.size()) return fail(RT_ERR_INVALID_ARG, "primitive %zu: material out of range", i);
+        if (p.light_index >= (int32_t)s->lights.size()) return fail(RT_ERR_INVALID_ARG, "primitive %zu: light out of range", i);
+        if (p.kind == RT_PRIM_TRIANGLE) {
+            if (p.mesh_index >= s->meshes.size()) return fail(RT_ERR_INVALID_ARG, "primitive %zu: mesh out of range", i);
+            if ((size_t)p.tri_ind + 2 >= s->meshes[p.mesh_index].ind.size())
+                return fail(RT_ERR_INVALID_ARG, "primitive %zu: tri_ind out of range", i);
+        } else if (p.kind != RT_PRIM_SPHERE) {
+            if (p.xform_index >= (int32_t)s->xforms.size()) return fail(RT_ERR_INVALID_ARG, "primitive %zu: transform out of range", i);
+        }
+    }
+    for (size_t i = 0; i < s->lights.size(); i++) {
+        const rt_light& l = s->lights[i];
+        if (l.kind != RT_LIGHT_DIFFUSE) return fail(RT_ERR_UNSUPPORTED, "light %zu: only Light::Diffuse is in scope", i);
+        if (l.prim_index >= s->prims.size()) return fail(RT_ERR_INVALID_ARG, "light %zu: primitive out of range", i);
+    }
+    return RT_OK;
+}
+
+int rt_scene_commit(rt_scene* s) {
+    SCENE_MUTABLE(s);
+    int rc = validate_scene(s);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    BvhOut bvh;
+    build_bvh(s->prims.data(), s->prims.size(), bvh);
+    if (bvh.depth > (uint32_t)kMaxBvhDepth) return fail(RT_ERR_UNSUPPORTED, "BVH depth %u exceeds the traversal stack", bvh.depth);
+    // leaf-ordered triangle vertices + ids
+    const size_t np = s->prims.size();
+    std::vector<uint32_t> leaf_prim(np);
+    std::vector<double> leaf_tri(np * 9, 0.0);
+    uint64_t n_tri = 0;
+    for (size_t i = 0; i < np; i++) {
+        const uint32_t id = bvh.order[i];
+        const rt_primitive& p = s->prims[id];
+        if (p.kind == RT_PRIM_TRIANGLE) {
+            const auto& m = s->meshes[p.mesh_index];
+            for (int v = 0; v < 3; v++) {
+                const uint32_t vi = m.ind[p.tri_ind + v];
+                for (int a = 0; a < 3; a++) leaf_tri[i * 9 + v * 3 + a] = m.p[3 * vi + a];
+            }
+            leaf_prim[i] = id;
+            n_tri++;
+        } else {
+            leaf_prim[i] = id | kLeafOther;
+        }
+    }
+    s->info = rt_scene_info{};
+    DevScene& d = s->dev;
+    d = DevScene{};
+    if ((rc = upload(s, bvh.nodes.data(), bvh.nodes.size(), &d.nodes)) != RT_OK) return rc;
+    if ((rc = upload(s, leaf_prim.data(), leaf_prim.size(), &d.leaf_prim)) != RT_OK) return rc;
+    if ((rc = upload(s, leaf_tri.data(), leaf_tri.size(), &d.leaf_tri)) != RT_OK) return rc;
+    if ((rc = upload(s, s->prims.data(), s->prims.size(), &d.prims)) != RT_OK) return rc;
+    std::vector<DevMesh> dm(s->meshes.size());
+    uint32_t has_uv = 0;
+    for (size_t i = 0; i < s->meshes.size(); i++) {
+        auto& m = s->meshes[i];
+        if ((rc = upload(s, m.p.data(), m.p.size(), &dm[i].p)) != RT_OK) return rc;
+        if ((rc = upload(s, m.n.data(), m.n.size(), &dm[i].n)) != RT_OK) return rc;
+        if ((rc = upload(s, m.uv.data(), m.uv.size(), &dm[i].uv)) != RT_OK) return rc;
+        if ((rc = upload(s, m.ind.data(), m.ind.size(), &dm[i].ind)) != RT_OK) return rc;
+        if (!m.uv.empty()) has_uv = 1;
+    }
+    if ((rc = upload(s, dm.data(), dm.size(), &d.meshes)) != RT_OK) return rc;
+    if ((rc = upload(s, s->xforms.data(), s->xforms.size(), &d.xforms)) != RT_OK) return rc;
+    if ((rc = upload(s, s->mats.data(), s->mats.size(), &d.mats)) != RT_OK) return rc;
+    if ((rc = upload(s, s->texs.data(), s->texs.size(), &d.texs)) != RT_OK) return rc;
+    if ((rc = upload(s, s->lights.data(), s->lights.size(), &d.lights)) != RT_OK) return rc;
+    d.n_prims = (uint32_t)np;
+    d.n_lights = (uint32_t)s->lights.size();
+    d.n_nodes = (uint32_t)bvh.nodes.size();
+    d.mesh_has_uv = has_uv;
+    s->info.n_prims = np;
+    s->info.n_triangles = n_tri;
+    s->info.n_others = np - n_tri;
+    s->info.n_bvh_nodes = bvh.nodes.size();
+    s->info.bvh_depth = bvh.depth;
+    s->info.node_bytes = sizeof(DevNode);
+    s->info.tri_bytes = 9 * sizeof(double) + sizeof(uint32_t);
+    s->info.other_bytes = sizeof(rt_primitive) + sizeof(uint32_t);
+    s->committed = true;
+    return RT_OK;
+}
+
+int rt_scene_destroy(rt_scene* s) {
+    if (!s) return RT_OK;
+    (void)hipSetDevice(s->ctx->device);
+    for (void* p : s->allocs) (void)hipFree(p);
+    delete s;
+    return RT_OK;
+}
+
+int rt_scene_get_info(const rt_scene* s, rt_scene_info* out) {
+    if (!s || !out) return fail(RT_ERR_INVALID_ARG, "null argument");
+    if (!s->committed) return fail(RT_ERR_STATE, "scene is not committed");
+    *out = s->info;
+    return RT_OK;
+}
+
+static uint32_t next_pow2(uint32_t v) {  // sampler.rs:633-642
+    uint32_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+static hipEvent_t get_event(rt_context* c, size_t i) {
+    while (c->events.size() <= i) {
+        hipEvent_t ev;
+        if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+        c->events.push_back(ev);
+    }
+    return c->events[i];
+}
+
+static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const rt_render_cfg* cfg, double* d_rgb,
+                       uint32_t* d_n, hipStream_t stream, rt_stats* stats) {
+    const uint32_t W = cfg->width, H = cfg->height;
+    const uint32_t spp = next_pow2(cfg->spp);
+    uint32_t x0 = cfg->x0, y0 = cfg->y0, x1 = cfg->x1, y1 = cfg->y1;
+    if (x1 == 0 && y1 == 0) {
+        x0 = 0; y0 = 0; x1 = W; y1 = H;
+    }
+    const uint32_t ts = cfg->tile_size ? cfg->tile_size : 16;
+    const uint32_t world = cfg->tile_world ? cfg->tile_world : 1;
+    const uint32_t rank = cfg->tile_rank;
+    // owned pixels: tiles k (row-major) with k % world == rank; 16-wide rows inside a tile
+    std::vector<uint32_t> pix;
+    const uint32_t tw = (W + ts - 1) / ts, th = (H + ts - 1) / ts;
+    for (uint32_t k = 0; k < tw * th; k++) {
+        if (k % world != rank) continue;
+        const uint32_t tx = k % tw, ty = k / tw;
+        for (uint32_t y = 0; y < ts; y++)
+            for (uint32_t x = 0; x < ts; x++) {
+                const uint32_t px = tx * ts + x, py = ty * ts + y;
+                if (px < x0 || px >= x1 || py < y0 || py >= y1) continue;
+                pix.push_back(py * W + px);
+            }
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(d_rgb, 0, sizeof(double) * 3 * (size_t)W * H, stream));
+    HIP_TRY(hipMemsetAsync(d_n, 0, sizeof(uint32_t) * (size_t)W * H, stream));
+    HIP_TRY(hipMemsetAsync(c->stats, 0, sizeof(DevStats), stream));
+    const size_t NP = pix.size();
+    double kernel_ms = 0.0, trace_ms = 0.0;
+    uint64_t trace_launches = 0;
+    if (NP > 0) {
+        uint32_t P = cfg->paths_in_flight ? cfg->paths_in_flight : (1u << 22);
+        P = std::max<uint32_t>(64u, std::min<uint32_t>(P, 1u << 26));
+        P &= ~63u;
+        // chunk shape: PB pixels x spc samples
+        uint32_t PB, spc;
+        if (NP * (size_t)spp <= P) {
+            PB = (uint32_t)NP;
+            spc = spp;
+        } else if (NP <= P) {
+            PB = (uint32_t)NP;
+            spc = 1;
+            while ((size_t)PB * spc * 2 <= P && spc * 2 <= spp) spc *= 2;
+        } else {
+            PB = P;
+            spc = 1;
+        }
+        const uint32_t cap = (uint32_t)((((size_t)PB * spc) + 63) & ~(size_t)63);
+        int rc = ensure_ctx_capacity(c, cap);
+        if (rc != RT_OK) return rc;
+        if (c->pix_capacity < NP) {
+            if (c->pix_list) HIP_TRY(hipFree(c->pix_list));
+            c->pix_list = nullptr;
+            HIP_TRY(hipMalloc((void**)&c->pix_list, NP * sizeof(uint32_t)));
+            c->pix_capacity = NP;
+        }
+        HIP_TRY(hipMemcpyAsync(c->pix_list, pix.data(), NP * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        const uint32_t iters = cfg->max_depth + 1;
+        const bool count_trav = (cfg->flags & RT_RENDER_COUNT_TRAVERSAL) != 0;
+        const int trace_blocks = c->num_cus * 8;
+        size_t ev_i = 0;
+        hipEvent_t ev_begin = get_event(c, ev_i++), ev_end = get_event(c, ev_i++);
+        if (!ev_begin || !ev_end) return fail(RT_ERR_HIP, "hipEventCreate failed");
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_ev;
+        HIP_TRY(hipEventRecord(ev_begin, stream));
+        for (size_t pb = 0; pb < NP; pb += PB) {
+            const uint32_t npx = (uint32_t)std::min<size_t>(PB, NP - pb);
+            for (uint32_t sb = 0; sb < spp; sb += spc) {
+                ChunkDesc ck;
+                ck.n_pixels = npx;
+                ck.n_samples = spc;
+                ck.pixel_base = (uint32_t)pb;
+                ck.sample_base = sb;
+                ck.width = W;
+                ck.height = H;
+                ck.seed = cfg->seed;
+                const uint32_t total = npx * spc;
+                const uint32_t blocks = (total + 255) / 256;
+                HIP_TRY(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), stream));
+                hipLaunchKernelGGL(k_generate, dim3(blocks), dim3(256), 0, stream, c->st, *cam, ck, c->pix_list,
+                                   c->active[0], c->queue[0], c->ctl, c->stats);
+                for (uint32_t it = 0; it < iters; it++) {
+                    hipEvent_t a = get_event(c, ev_i++), b = get_event(c, ev_i++);
+                    if (!a || !b) return fail(RT_ERR_HIP, "hipEventCreate failed");
+                    HIP_TRY(hipEventRecord(a, stream));
+                    if (count_trav)
+                        hipLaunchKernelGGL(k_trace<true>, dim3(trace_blocks), dim3(256), 0, stream, s->dev, c->st,
+                                           c->queue[it & 1], c->ctl, (int)it, c->stats);
+                    else
+                        hipLaunchKernelGGL(k_trace<false>, dim3(trace_blocks), dim3(256), 0, stream, s->dev, c->st,
+                                           c->queue[it & 1], c->ctl, (int)it, c->stats);
+                    HIP_TRY(hipEventRecord(b, stream));
+                    trace_ev.emplace_back(a, b);
+                    trace_launches++;
+                    hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, stream, s->dev, c->st, c->ctl, (int)it,
+                                       cfg->max_depth, c->active[it & 1], c->active[(it + 1) & 1],
+                                       c->queue[(it + 1) & 1], c->stats);
+                }
+                hipLaunchKernelGGL(k_resolve, dim3((npx + 255) / 256), dim3(256), 0, stream, c->st, ck, c->pix_list,
+                                   d_rgb, d_n);
+                HIP_TRY(hipGetLastError());
+            }
+        }
+        HIP_TRY(hipEventRecord(ev_end, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev_begin, ev_end));
+        kernel_ms = ms;
+        for (auto& pr : trace_ev) {
+            HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+            trace_ms += ms;
+        }
+    } else {
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    if (stats) {
+        DevStats ds;
+        HIP_TRY(hipMemcpy(&ds, c->stats, sizeof(ds), hipMemcpyDeviceToHost));
+        std::memset(stats, 0, sizeof(*stats));
+        stats->paths = ds.paths;
+        stats->rays_extension = ds.r1;
+        stats->rays_shadow = ds.r2;
+        stats->rays_probe = ds.r3;
+        stats->vertices_shaded = ds.vertices;
+        stats->nodes_fetched = ds.nodes;
+        stats->tris_tested = ds.tris;
+        stats->others_tested = ds.others;
+        stats->kernel_ms = kernel_ms;
+        stats->trace_ms = trace_ms;
+        stats->trace_launches = trace_launches;
+    }
+    return RT_OK;
+}
+
+static int check_render_args(rt_context* c, rt_scene* s, const rt_camera* cam, const rt_render_cfg* cfg) {
+    if (!c || !s || !cam || !cfg) return fail(RT_ERR_INVALID_ARG, "rt_render: null argument");
+    if (s->ctx != c) return fail(RT_ERR_INVALID_ARG, "rt_render: scene belongs to another context");
+    if (!s->committed) return fail(RT_ERR_STATE, "rt_render: scene is not committed");
+    if (cfg->width == 0 || cfg->height == 0 || cfg->spp == 0) return fail(RT_ERR_INVALID_ARG, "rt_render: empty image or spp == 0");
+    if ((uint64_t)cfg->width * cfg->height >= (1ull << 30)) return fail(RT_ERR_UNSUPPORTED, "rt_render: image too large");
+    if (cfg->max_depth > 255) return fail(RT_ERR_UNSUPPORTED, "rt_render: max_depth > 255");
+    if (cfg->precision != RT_PRECISION_F64) return fail(RT_ERR_UNSUPPORTED, "rt_render: unknown precision");
+    if (!(cfg->x1 == 0 && cfg->y1 == 0) &&
+        (cfg->x1 > cfg->width || cfg->y1 > cfg->height || cfg->x0 > cfg->x1 || cfg->y0 > cfg->y1))
+        return fail(RT_ERR_INVALID_ARG, "rt_render: bad pixel window");
+    const uint32_t world = cfg->tile_world ? cfg->tile_world : 1;
+    if (cfg->tile_rank >= world) return fail(RT_ERR_INVALID_ARG, "rt_render: tile_rank >= tile_world");
+    return RT_OK;
+}
+
+int rt_render_device(rt_context* c, rt_scene* s, const rt_camera* cam, const rt_render_cfg* cfg, double* d_rgb_sum,
+                     uint32_t* d_n, void* hip_stream, rt_stats* stats) {
+    int rc = check_render_args(c, s, cam, cfg);
+    if (rc != RT_OK) return rc;
+    if (!d_rgb_sum || !d_n) return fail(RT_ERR_INVALID_ARG, "rt_render_device: null film pointer");
+    return render_impl(c, s, cam, cfg, d_rgb_sum, d_n, hip_stream ? (hipStream_t)hip_stream : c->stream, stats);
+}
+
+int rt_render(rt_context* c, rt_scene* s, const rt_camera* cam, const rt_render_cfg* cfg, double* rgb_sum, uint32_t* n,
+              rt_stats* stats) {
+    int rc = check_render_args(c, s, cam, cfg);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t npix = (size_t)cfg->width * cfg->height;
+    double* d_rgb = nullptr;
+    uint32_t* d_n = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_rgb, npix * 3 * sizeof(double)));
+    hipError_t e = hipMalloc((void**)&d_n, npix * sizeof(uint32_t));
+    if (e != hipSuccess) {
+        (void)hipFree(d_rgb);
+        return fail(RT_ERR_OOM, "hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    rc = render_impl(c, s, cam, cfg, d_rgb, d_n, c->stream, stats);
+    if (rc == RT_OK && rgb_sum) {
+        e = hipMemcpy(rgb_sum, d_rgb, npix * 3 * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(RT_ERR_HIP, "film download failed: %s", hipGetErrorString(e));
+    }
+    if (rc == RT_OK && n) {
+        e = hipMemcpy(n, d_n, npix * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(RT_ERR_HIP, "film download failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d_rgb);
+    (void)hipFree(d_n);
+    return rc;
+}
+
+int rt_intersect_batch(rt_context* c, rt_scene* s, const rt_ray* rays, uint64_t n, rt_hit* hits) {
+    if (!c || !s || (n && (!rays || !hits))) return fail(RT_ERR_INVALID_ARG, "rt_intersect_batch: null argument");
+    if (!s->committed) return fail(RT_ERR_STATE, "rt_intersect_batch: scene is not committed");
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    rt_ray* d_rays = nullptr;
+    rt_hit* d_hits = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_rays, n * sizeof(rt_ray)));
+    hipError_t e = hipMalloc((void**)&d_hits, n * sizeof(rt_hit));
+    if (e != hipSuccess) {
+        (void)hipFree(d_rays);
+        return fail(RT_ERR_OOM, "hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    int rc = RT_OK;
+    e = hipMemcpyAsync(d_rays, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_intersect_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, s->dev, d_rays, n, d_hits);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(hits, d_hits, n * sizeof(rt_hit), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = fail(RT_ERR_HIP, "rt_intersect_batch: %s", hipGetErrorString(e));
+    (void)hipFree(d_rays);
+    (void)hipFree(d_hits);
+    return rc;
+}
+
+int rt_resolve_rgb8(rt_context* c, const double* rgb_sum, const uint32_t* n, uint32_t width, uint32_t height,
+                    uint8_t* rgb8) {
+    if (!c || !rgb_sum || !n || !rgb8 || width == 0 || height == 0) return fail(RT_ERR_INVALID_ARG, "rt_resolve_rgb8: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t npix = (size_t)width * height;
+    double* d_rgb = nullptr;
+    uint32_t* d_n = nullptr;
+    uint8_t* d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_rgb, npix * 3 * sizeof(double)));
+    hipError_t e = hipMalloc((void**)&d_n, npix * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_out, npix * 3);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rgb, rgb_sum, npix * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_n, n, npix * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_tonemap, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, c->stream, d_rgb, d_n, (uint64_t)npix, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(rgb8, d_out, npix * 3, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_rgb);
+    if (d_n) (void)hipFree(d_n);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, "rt_resolve_rgb8: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+}  // extern "C"

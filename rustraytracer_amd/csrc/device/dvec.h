@@ -1,0 +1,66 @@
+// dvec.h -- f64 3-vectors, Rust-style min/max and the counter RNG for gfx950 device
+// code (also compiled for the host by hipcc for the BVH builder's helpers).
+// Every expression keeps the reference's evaluation order; the translation unit is
+// built with -ffp-contract=off so that no mul+add pair is fused (numerical
+// contract, include/rt_abi.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../../include/rt_abi.h"
+#include "../../../include/rt_detmath.h"
+
+#define RTD __device__ __forceinline__
+#define RTDN __device__ __noinline__
+
+namespace rtd {
+
+// consts.rs:30-42
+constexpr double kPi = 3.14159265358979;
+constexpr double kSmall = 0.001;
+constexpr double kInf = 1e308;
+constexpr double kInvPi = 1.0 / kPi;
+
+// f64::max / f64::min: the non-NaN operand wins
+RTD double rmax(double a, double b) { return (a != a) ? b : ((b != b) ? a : (a < b ? b : a)); }
+RTD double rmin(double a, double b) { return (a != a) ? b : ((b != b) ? a : (b < a ? b : a)); }
+RTD double clampd(double x, double lo, double hi) { return rmin(rmax(x, lo), hi); }  // util.rs:28-30
+RTD double absd(double x) { return __builtin_fabs(x); }
+
+struct D3 {
+    double x, y, z;
+};
+RTD D3 d3(double x, double y, double z) { return D3{x, y, z}; }
+RTD D3 operator+(D3 a, D3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+RTD D3 operator-(D3 a, D3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+RTD D3 operator-(D3 a) { return {-a.x, -a.y, -a.z}; }
+RTD D3 operator*(D3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+RTD D3 operator*(double s, D3 a) { return {s * a.x, s * a.y, s * a.z}; }
+RTD D3 operator/(D3 a, double s) { return {a.x / s, a.y / s, a.z / s}; }
+RTD D3 cmul(D3 a, D3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+RTD D3 cdiv(D3 a, D3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+RTD double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RTD D3 cross(D3 a, D3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+RTD double norm2(D3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+RTD double norm(D3 a) { return dm_sqrt(norm2(a)); }
+RTD D3 normalize(D3 a) { return a / norm(a); }
+RTD bool is_black(D3 a) { return a.x == 0.0 && a.y == 0.0 && a.z == 0.0; }
+RTD D3 black() { return {0.0, 0.0, 0.0}; }
+RTD D3 white() { return {1.0, 1.0, 1.0}; }
+RTD double comp(D3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+// RNG block of include/rt_abi.h
+RTD uint64_t rng_mix(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+RTD uint64_t rng_init(uint64_t seed, uint64_t pixel, uint64_t sample) {
+    return rng_mix(rng_mix(seed * RT_RNG_G + pixel) + sample * RT_RNG_H + RT_RNG_J);
+}
+RTD double rng_next(uint64_t& s) {
+    s += RT_RNG_G;
+    return (double)(rng_mix(s) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+}  // namespace rtd

@@ -1,0 +1,482 @@
+// geom.h -- ray/primitive tests and the closest-hit BVH traversal for gfx950.
+//
+// Replaces, with identical results (tests/test_gpu_intersect.py):
+//   BoundingBox::intersects        src/hittable.rs:494-508   -> slab()
+//   Mesh::intersects_triangle      src/hittable.rs:292-452   -> tri_core() + tri_record()
+//   sphere_intersect / record      src/intersects.rs:177-258 -> sphere_core() + sphere_record()
+//   {xy,xz,yz}_rect_intersect      src/intersects.rs:10-175  -> rect_core() + rect_record()
+//   Primitive::intersects          src/primitive.rs:247-316  -> prim_intersects()
+//   BvhNode::intersects            src/hittable.rs:591-634   -> closest_hit()
+//
+// The reference's traversal is exhaustive (both children always visited, no tmax
+// shrinking), so its result is "closest hit over every primitive whose own AABB
+// passes the slab test on [tmin, 1e308]".  closest_hit() returns exactly that with
+// an ordered, pruned walk over our own BVH: the f64 slab test is monotone in the
+// box, so a parent box (a superset, rounded outward to f32) passes whenever the
+// leaf's f64 box does; pruning uses [tmin, best_t*(1+1e-9)] so rounding between
+// the box entry and the primitive's own t can never drop a closer hit.
+#pragma once
+#include "dvec.h"
+#include "scene_dev.h"
+
+namespace rtd {
+
+struct HitRec {  // hittable.rs:50-72, the fields the path reads
+    double t;
+    D3 n, p;
+    bool front;
+    double u, v;
+    uint32_t mat;
+    int32_t prim;
+    D3 sh_n, sh_dpdu;
+    D3 wo;
+};
+
+// util.rs:567-576
+RTD void make_coordinate_system(D3 v1, D3& v2, D3& v3) {
+    if (absd(v1.x) > absd(v1.y))
+        v2 = d3(-v1.z, 0.0, v1.x) * (1.0 / dm_sqrt(v1.x * v1.x + v1.z * v1.z));
+    else
+        v2 = d3(0.0, v1.z, -v1.y) * (1.0 / dm_sqrt(v1.y * v1.y + v1.z * v1.z));
+    v3 = cross(v1, v2);
+}
+RTD D3 face_forward(D3 n, D3 v) { return dot(n, v) < 0.0 ? -n : n; }  // util.rs:578-581
+
+RTD D3 xf_point(const double* m, D3 p) {
+    return d3(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
+              m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]);
+}
+RTD D3 xf_vector(const double* m, D3 v) {
+    return d3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z,
+              m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+
+// hittable.rs:494-508 with 1/dir hoisted per ray (same IEEE value as the per-node divide).
+// Returns pass/fail; `entry` = final tmin (the box entry parameter).
+RTD bool slab(double b0x, double b0y, double b0z, double b1x, double b1y, double b1z, D3 o, D3 inv, double tmin,
+              double tmax, double& entry) {
+    double v1 = (b0x - o.x) * inv.x, v2 = (b1x - o.x) * inv.x;
+    tmin = rmax(tmin, rmin(v1, v2));
+    tmax = rmin(tmax, rmax(v1, v2));
+    if (tmax <= tmin) return false;
+    v1 = (b0y - o.y) * inv.y;
+    v2 = (b1y - o.y) * inv.y;
+    tmin = rmax(tmin, rmin(v1, v2));
+    tmax = rmin(tmax, rmax(v1, v2));
+    if (tmax <= tmin) return false;
+    v1 = (b0z - o.z) * inv.z;
+    v2 = (b1z - o.z) * inv.z;
+    tmin = rmax(tmin, rmin(v1, v2));
+    tmax = rmin(tmax, rmax(v1, v2));
+    if (tmax <= tmin) return false;
+    entry = tmin;
+    return true;
+}
+
+// ------------------------------------------------------------------ triangle
+// hittable.rs:300-362: sheared edge-function test (Q4, Q6).  tmin is ignored by the reference.
+RTD bool tri_core(D3 p0, D3 p1, D3 p2, D3 o, D3 dir, double tmax, double& t, double& b0, double& b1, double& b2) {
+    D3 p0t = p0 - o, p1t = p1 - o, p2t = p2 - o;
+    double ax = absd(dir.x), ay = absd(dir.y), az = absd(dir.z);
+    int kz = 0;
+    double best = ax;
+    if (ay > best) { best = ay; kz = 1; }
+    if (az > best) { best = az; kz = 2; }
+    int kx = (kz + 1) % 3, ky = (kx + 1) % 3;
+    D3 d = d3(comp(dir, kx), comp(dir, ky), comp(dir, kz));
+    p0t = d3(comp(p0t, kx), comp(p0t, ky), comp(p0t, kz));
+    p1t = d3(comp(p1t, kx), comp(p1t, ky), comp(p1t, kz));
+    p2t = d3(comp(p2t, kx), comp(p2t, ky), comp(p2t, kz));
+    double s_x = -d.x / d.z, s_y = -d.y / d.z, s_z = 1.0 / d.z;
+    p0t.x += s_x * p0t.z; p0t.y += s_y * p0t.z;
+    p1t.x += s_x * p1t.z; p1t.y += s_y * p1t.z;
+    p2t.x += s_x * p2t.z; p2t.y += s_y * p2t.z;
+    double e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+    double e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+    double e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+    if ((e0 < 0.0 || e1 < 0.0 || e2 < 0.0) && (e0 > 0.0 || e1 > 0.0 || e2 > 0.0)) return false;
+    double det = e0 + e1 + e2;
+    if (absd(det) < kSmall / 10000.0) return false;
+    p0t.z *= s_z; p1t.z *= s_z; p2t.z *= s_z;
+    double t_scaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+    if (det < 0.0 && (t_scaled >= 0.0 || t_scaled < tmax * det))
+        return false;
+    else if (det > 0.0 && (t_scaled <= 0.0 || t_scaled > tmax * det))
+        return false;
+    double inv_det = 1.0 / det;
+    b0 = e0 * inv_det;
+    b1 = e1 * inv_det;
+    b2 = e2 * inv_det;
+    t = t_scaled * inv_det;
+    if (t < kSmall / 10.0) return false;
+    return true;
+}
+
+struct TriUv {
+    double u0, v0, u1, v1, u2, v2;
+};
+RTD TriUv tri_uvs(const DevMesh& m, uint32_t i1, uint32_t i2, uint32_t i3) {  // hittable.rs:454-468
+    TriUv r{0.0, 0.0, 1.0, 0.0, 1.0, 1.0};
+    if (m.uv) {
+        r.u0 = m.uv[2 * i1]; r.v0 = m.uv[2 * i1 + 1];
+        r.u1 = m.uv[2 * i2]; r.v1 = m.uv[2 * i2 + 1];
+        r.u2 = m.uv[2 * i3]; r.v2 = m.uv[2 * i3 + 1];
+    }
+    return r;
+}
+// hittable.rs:367-386: the only rejection after t is accepted (degenerate triangle
+// under a degenerate uv map).  Also yields dpdu/dpdv.
+RTD bool tri_dpdu(D3 p0, D3 p1, D3 p2, const TriUv& uv, D3& dpdu, D3& dpdv) {
+    double duv02x = uv.u0 - uv.u2, duv02y = uv.v0 - uv.v2;
+    double duv12x = uv.u1 - uv.u2, duv12y = uv.v1 - uv.v2;
+    D3 dp02 = p0 - p2, dp12 = p1 - p2;
+    double determinant = duv02x * duv12y - duv02y * duv12x;
+    if (absd(determinant) < kSmall / 10000.0) {
+        D3 n = cross(p2 - p0, p1 - p0);
+        if (norm2(n) == 0.0) return false;
+        make_coordinate_system(n, dpdu, dpdv);
+    } else {
+        double invd = 1.0 / determinant;
+        dpdu = (duv12y * dp02 - duv02y * dp12) * invd;
+        dpdv = (-duv12x * dp02 + duv02x * dp12) * invd;
+    }
+    return true;
+}
+
+RTD void load_tri(const DevScene& sc, const rt_primitive& pr, D3& p0, D3& p1, D3& p2, uint32_t& i1, uint32_t& i2,
+                  uint32_t& i3) {
+    const DevMesh& m = sc.meshes[pr.mesh_index];
+    i1 = m.ind[pr.tri_ind];
+    i2 = m.ind[pr.tri_ind + 1];
+    i3 = m.ind[pr.tri_ind + 2];
+    p0 = d3(m.p[3 * i1], m.p[3 * i1 + 1], m.p[3 * i1 + 2]);
+    p1 = d3(m.p[3 * i2], m.p[3 * i2 + 1], m.p[3 * i2 + 2]);
+    p2 = d3(m.p[3 * i3], m.p[3 * i3 + 1], m.p[3 * i3 + 2]);
+}
+
+// HitRecord::new + set_front pieces (hittable.rs:75-117, 186-189)
+RTD void hit_new(HitRec& h, D3 p, double u, double v, D3 wo, D3 dpdu, D3 dpdv, double t, uint32_t mat) {
+    D3 n = normalize(cross(dpdu, dpdv));
+    h.p = p;
+    h.n = n;
+    h.t = t;
+    h.front = false;
+    h.u = u;
+    h.v = v;
+    h.mat = mat;
+    h.wo = wo;
+    h.sh_n = n;
+    h.sh_dpdu = normalize(dpdu);
+    h.prim = 0;
+}
+RTD void set_front(HitRec& h, D3 dir) {
+    h.front = dot(dir, h.n) < 0.0;
+    if (!h.front) h.n = -h.n;
+}
+
+// hittable.rs:363-451: the differential-geometry block, run for the winning hit only.
+RTD bool tri_record(const DevScene& sc, const rt_primitive& pr, D3 o, D3 dir, double tmax, HitRec& h) {
+    D3 p0, p1, p2;
+    uint32_t i1, i2, i3;
+    load_tri(sc, pr, p0, p1, p2, i1, i2, i3);
+    double t, b0, b1, b2;
+    if (!tri_core(p0, p1, p2, o, dir, tmax, t, b0, b1, b2)) return false;
+    const DevMesh& m = sc.meshes[pr.mesh_index];
+    TriUv uv = tri_uvs(m, i1, i2, i3);
+    D3 dpdu, dpdv;
+    if (!tri_dpdu(p0, p1, p2, uv, dpdu, dpdv)) return false;
+    D3 dp02 = p0 - p2, dp12 = p1 - p2;
+    D3 p_hit = b0 * p0 + b1 * p1 + b2 * p2;
+    double u_hit = b0 * uv.u0 + b1 * uv.u1 + b2 * uv.u2;
+    double v_hit = b0 * uv.v0 + b1 * uv.v1 + b2 * uv.v2;
+    D3 normal;
+    if (!m.n) {
+        normal = cross(dp02, dp12);
+    } else {
+        D3 n1 = d3(m.n[3 * i1], m.n[3 * i1 + 1], m.n[3 * i1 + 2]);
+        D3 n2 = d3(m.n[3 * i2], m.n[3 * i2 + 1], m.n[3 * i2 + 2]);
+        D3 n3 = d3(m.n[3 * i3], m.n[3 * i3 + 1], m.n[3 * i3 + 2]);
+        normal = b0 * n1 + b1 * n2 + b2 * n3;
+    }
+    hit_new(h, p_hit, u_hit, v_hit, -dir, dpdu, dpdv, t, pr.mat_index);
+    h.n = normalize(cross(dp02, dp12));
+    h.sh_n = normalize(normal);
+    D3 ss = normalize(dpdu);
+    D3 ts = normalize(cross(h.sh_n, ss));
+    if (norm2(ts) > 0.0) {
+        ss = normalize(cross(ts, h.sh_n));
+    } else {
+        D3 a, b;
+        make_coordinate_system(h.sh_n, a, b);
+        ss = normalize(a);
+        ts = normalize(b);
+    }
+    D3 n = normalize(cross(ss, ts));  // set_shading_geometry(.., is_auth = true)
+    h.sh_n = n;
+    h.n = face_forward(h.n, h.sh_n);
+    h.sh_dpdu = ss;
+    set_front(h, dir);
+    h.u = u_hit;
+    h.v = v_hit;
+    return true;
+}
+
+// -------------------------------------------------------------------- rects
+// intersects.rs:10-175.  Outputs t and the in-plane coordinates.
+RTD bool rect_core(const DevScene& sc, const rt_primitive& pr, D3 o, D3 dir, double t0, double t1, double& t,
+                   double& a, double& b, D3& to, D3& td) {
+    to = o;
+    td = dir;
+    if (pr.xform_index >= 0) {  // Ray::transform (geometry.rs:231-235) with the stored inverse
+        const rt_xform& xf = sc.xforms[pr.xform_index];
+        td = xf_vector(xf.inv, dir);
+        to = xf_point(xf.inv, o);
+    }
+    double k = pr.v[4];
+    if (pr.kind == RT_PRIM_XY_RECT) {
+        t = (k - to.z) / td.z;
+        if (t < t0 || t > t1) return false;
+        a = to.x + t * td.x;
+        b = to.y + t * td.y;
+    } else if (pr.kind == RT_PRIM_XZ_RECT) {
+        t = (k - to.y) / td.y;
+        if (t < t0 || t > t1) return false;
+        a = to.x + t * td.x;
+        b = to.z + t * td.z;
+    } else {
+        t = (k - to.x) / td.x;
+        if (t < t0 || t > t1) return false;
+        a = to.y + t * td.y;
+        b = to.z + t * td.z;
+    }
+    if (a < pr.v[0] || b < pr.v[1] || a > pr.v[2] || b > pr.v[3]) return false;
+    return true;
+}
+RTD bool rect_record(const DevScene& sc, const rt_primitive& pr, D3 o, D3 dir, double t0, double t1, HitRec& h) {
+    double t, a, b;
+    D3 to, td;
+    if (!rect_core(sc, pr, o, dir, t0, t1, t, a, b, to, td)) return false;
+    D3 dpdu, dpdv;
+    if (pr.kind == RT_PRIM_XY_RECT) {
+        dpdu = d3(1, 0, 0);
+        dpdv = d3(0, 1, 0);
+    } else if (pr.kind == RT_PRIM_XZ_RECT) {
+        dpdu = d3(1, 0, 0);
+        dpdv = d3(0, 0, 1);
+    } else {
+        dpdu = d3(0, 1, 0);
+        dpdv = d3(0, 0, 1);
+    }
+    double u = (a - pr.v[0]) / (pr.v[2] - pr.v[0]), v = (b - pr.v[1]) / (pr.v[3] - pr.v[1]);
+    D3 p = to + td * t;
+    if (pr.xform_index >= 0) {
+        const rt_xform& xf = sc.xforms[pr.xform_index];
+        p = xf_point(xf.fwd, p);
+        dpdu = xf_vector(xf.fwd, dpdu);
+        dpdv = xf_vector(xf.fwd, dpdv);
+    }
+    hit_new(h, p, u, v, -dir, dpdu, dpdv, t, pr.mat_index);
+    set_front(h, dir);
+    return true;
+}
+
+// ------------------------------------------------------------------- sphere
+// intersects.rs:177-213
+RTD bool sphere_core(const rt_primitive& pr, D3 o, D3 dir, double tmin, double tmax, double& t) {
+    D3 center = d3(pr.v[0], pr.v[1], pr.v[2]);
+    double r = pr.v[3];
+    D3 diff = o - center;
+    double a = dot(dir, dir);
+    double b = dot(diff, dir);
+    double c = dot(diff, diff) - r * r;
+    double disc = b * b - a * c;
+    if (disc < 0.0) return false;
+    double inv_a = 1.0 / a;
+    double root = dm_sqrt(disc);
+    double ans = (-b - root) * inv_a;
+    if (ans < tmax && ans > tmin) {
+        t = ans;
+        return true;
+    }
+    ans = (-b + root) * inv_a;
+    if (ans < tmax && ans > tmin) {
+        t = ans;
+        return true;
+    }
+    return false;
+}
+// intersects.rs:216-258 (Q8)
+RTDN bool sphere_record(const rt_primitive& pr, D3 o, D3 dir, double tmin, double tmax, HitRec& h) {
+    double t;
+    if (!sphere_core(pr, o, dir, tmin, tmax, t)) return false;
+    D3 center = d3(pr.v[0], pr.v[1], pr.v[2]);
+    double r = pr.v[3];
+    D3 to = o - center;
+    D3 p = to + dir * t;
+    p = p * r / norm(p);
+    if (p.x == 0.0 && p.y == 0.0) p.x = 1e-5 * r;
+    double phi = dm_atan2(p.y, p.x);
+    if (phi < 0.0) phi = phi + 2.0 * kPi;
+    double phi_max = 2.0 * kPi;
+    double theta_min = 0.0, theta_max = kPi;
+    double u = phi / phi_max;
+    double theta = dm_acos(clampd(p.z / r, -1.0, 1.0));
+    double v = (theta - theta_min) / (theta_max - theta_min);
+    double z_r = dm_sqrt(p.x * p.x + p.y * p.y);
+    double inv_z_r = 1.0 / z_r;
+    double cos_phi = p.x * inv_z_r;
+    double sin_phi = p.y * inv_z_r;
+    D3 dpdu = d3(-phi_max * p.y, phi_max * p.x, 0.0);
+    D3 dpdv = (theta_max - theta_min) * d3(p.z * cos_phi, p.z * sin_phi, -r * dm_sin(theta));
+    hit_new(h, p, u, v, -dir, dpdu, dpdv, t, pr.mat_index);
+    set_front(h, dir);
+    h.p = h.p + center;
+    return true;
+}
+
+// primitive.rs:372-425 intersects_obj: full record of ONE primitive, no prim_index stamp
+RTD bool intersects_obj(const DevScene& sc, const rt_primitive& pr, D3 o, D3 dir, double tmin, double tmax,
+                        HitRec& h) {
+    if (pr.kind == RT_PRIM_TRIANGLE) return tri_record(sc, pr, o, dir, tmax, h);
+    if (pr.kind == RT_PRIM_SPHERE) return sphere_record(pr, o, dir, tmin, tmax, h);
+    return rect_record(sc, pr, o, dir, tmin, tmax, h);
+}
+// primitive.rs:247-316
+RTD bool prim_intersects(const DevScene& sc, int32_t index, D3 o, D3 dir, double tmin, double tmax, HitRec& h) {
+    const rt_primitive& pr = sc.prims[index];
+    if (!intersects_obj(sc, pr, o, dir, tmin, tmax, h)) return false;
+    if (pr.flip) h.front = !h.front;
+    h.prim = index;
+    return true;
+}
+
+// ---------------------------------------------------------------- traversal
+RTD float float_lower(double t) {  // largest float <= t, for t >= 0
+    float f = (float)t;
+    if ((double)f > t) f = __uint_as_float(__float_as_uint(f) - 1u);
+    return f;
+}
+
+struct TravCount {
+    uint32_t nodes, tris, others;
+};
+
+// Closest hit; ties in t go to the larger prim index (ABI tie rule).
+// Returns prim index or -1; t_out = hit parameter.
+template <bool COUNT>
+RTD int32_t closest_hit(const DevScene& sc, D3 o, D3 dir, double tmin, double tmax, double& t_out, TravCount* tc) {
+    int32_t best_prim = -1;
+    double best_t = tmax;
+    if (sc.n_nodes == 0) {
+        t_out = tmax;
+        return -1;
+    }
+    const D3 inv = d3(1.0 / dir.x, 1.0 / dir.y, 1.0 / dir.z);
+    int32_t stack_node[64];
+    float stack_t[64];
+    int sp = 0;
+    int32_t cur = 0;
+    for (;;) {
+        const double lim = best_prim >= 0 ? best_t * (1.0 + 1e-9) : tmax;
+        if (cur >= 0) {
+            const float4* np = reinterpret_cast<const float4*>(&sc.nodes[cur]);
+            const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+            if (COUNT) tc->nodes++;
+            const int32_t left = __float_as_int(n3.x), right = __float_as_int(n3.y);
+            double el = 0.0, er = 0.0;
+            bool hl = left != kNoChild &&
+                      slab((double)n0.x, (double)n0.y, (double)n0.z, (double)n0.w, (double)n1.x, (double)n1.y, o, inv,
+                           tmin, lim, el);
+            bool hr = right != kNoChild &&
+                      slab((double)n1.z, (double)n1.w, (double)n2.x, (double)n2.y, (double)n2.z, (double)n2.w, o, inv,
+                           tmin, lim, er);
+            if (hl && hr) {
+                int32_t nearc = left, farc = right;
+                double ef = er;
+                if (er < el) {
+                    nearc = right;
+                    farc = left;
+                    ef = el;
+                }
+                stack_node[sp] = farc;
+                stack_t[sp] = float_lower(ef);
+                sp++;
+                cur = nearc;
+                continue;
+            } else if (hl) {
+                cur = left;
+                continue;
+            } else if (hr) {
+                cur = right;
+                continue;
+            }
+        } else {
+            // leaf: -1 - (first*8 + count-1)
+            const uint32_t code = (uint32_t)(-1 - cur);
+            const uint32_t first = code >> 3, count = (code & 7u) + 1u;
+            for (uint32_t i = 0; i < count; i++) {
+                const uint32_t e = sc.leaf_prim[first + i];
+                double t;
+                int32_t pi;
+                if (!(e & kLeafOther)) {
+                    const double* tv = sc.leaf_tri + (size_t)(first + i) * 9;
+                    const D3 p0 = d3(tv[0], tv[1], tv[2]), p1 = d3(tv[3], tv[4], tv[5]), p2 = d3(tv[6], tv[7], tv[8]);
+                    if (COUNT) tc->tris++;
+                    // the reference tests the leaf's own f64 box on the ORIGINAL interval (hittable.rs:625)
+                    double en;
+                    if (!slab(rmin(p0.x, rmin(p1.x, p2.x)), rmin(p0.y, rmin(p1.y, p2.y)), rmin(p0.z, rmin(p1.z, p2.z)),
+                              rmax(p0.x, rmax(p1.x, p2.x)), rmax(p0.y, rmax(p1.y, p2.y)), rmax(p0.z, rmax(p1.z, p2.z)),
+                              o, inv, tmin, tmax, en))
+                        continue;
+                    double b0, b1, b2;
+                    if (!tri_core(p0, p1, p2, o, dir, tmax, t, b0, b1, b2)) continue;
+                    pi = (int32_t)e;
+                    if (sc.mesh_has_uv) {  // rare path: uv-degenerate rejection (hittable.rs:373-378)
+                        const rt_primitive& pr = sc.prims[pi];
+                        const DevMesh& m = sc.meshes[pr.mesh_index];
+                        if (m.uv) {
+                            TriUv uv = tri_uvs(m, m.ind[pr.tri_ind], m.ind[pr.tri_ind + 1], m.ind[pr.tri_ind + 2]);
+                            D3 du, dv;
+                            if (!tri_dpdu(p0, p1, p2, uv, du, dv)) continue;
+                        }
+                    }
+                } else {
+                    pi = (int32_t)(e & ~kLeafOther);
+                    const rt_primitive& pr = sc.prims[pi];
+                    if (COUNT) tc->others++;
+                    double en;
+                    if (!slab(pr.bbox_min[0], pr.bbox_min[1], pr.bbox_min[2], pr.bbox_max[0], pr.bbox_max[1],
+                              pr.bbox_max[2], o, inv, tmin, tmax, en))
+                        continue;
+                    if (pr.kind == RT_PRIM_SPHERE) {
+                        if (!sphere_core(pr, o, dir, tmin, tmax, t)) continue;
+                    } else {
+                        double a, b;
+                        D3 to, td;
+                        if (!rect_core(sc, pr, o, dir, tmin, tmax, t, a, b, to, td)) continue;
+                    }
+                }
+                if (best_prim < 0 || t < best_t || (t == best_t && pi > best_prim)) {
+                    best_t = t;
+                    best_prim = pi;
+                }
+            }
+        }
+        // pop, skipping subtrees that now start beyond the best hit
+        bool got = false;
+        const double lim2 = best_prim >= 0 ? best_t * (1.0 + 1e-9) : tmax;
+        while (sp > 0) {
+            sp--;
+            if ((double)stack_t[sp] <= lim2) {
+                cur = stack_node[sp];
+                got = true;
+                break;
+            }
+        }
+        if (!got) break;
+    }
+    t_out = best_t;
+    return best_prim;
+}
+
+}  // namespace rtd

@@ -1,0 +1,391 @@
+// kernels.hip -- the wavefront path-tracing kernels for gfx950 (wave64).
+//
+// One chunk = up to `paths_in_flight` camera samples.  Per bounce iteration:
+//   k_trace  persistent waves pull 64-ray batches from the ray queue (one atomic per
+//            wave) and run the closest-hit traversal for the three root call sites
+//            of SURVEY.md 3.2: R1 extension (integrator.rs:388), R2 shadow
+//            (hittable.rs:25-39, Q13: closest hit, compared by prim index), R3 MIS
+//            probe (integrator.rs:615).  Output: one prim index per ray.
+//   k_shade  one lane per live path: folds the previous vertex's direct-light terms
+//            using the R2/R3 results, rebuilds the winning hit's record, applies the
+//            emitted-light rule, builds the BSDF, samples one light + MIS
+//            (integrator.rs:530-659), samples the continuation, Russian roulette
+//            (integrator.rs:375-445), then compacts survivors and their rays into the
+//            next queues with __ballot/__popcll prefix sums (one atomic per wave).
+// The R2/R3 results never influence control flow or RNG draws of the path, only
+// additions into L, which is why they can be traced one iteration late.
+// Film: k_resolve sums each pixel's samples in sample order in f64 -- the order of
+// util::increment_color (util.rs:208-232) -- so images are bit-reproducible and
+// independent of how tiles are split over GPUs.
+#include "shading.h"
+
+namespace rtd {
+
+struct Ctl {
+    uint32_t n_active[264];
+    uint32_t n_rays[264];
+    uint32_t head[264];
+};
+
+struct ChunkDesc {
+    uint32_t n_pixels;     // pixels in this chunk (PB)
+    uint32_t n_samples;    // samples per pixel in this chunk (spc)
+    uint32_t pixel_base;   // offset into pix_list
+    uint32_t sample_base;  // first sample index
+    uint32_t width, height;
+    uint64_t seed;
+};
+
+RTD D3 ld3(const double* x, const double* y, const double* z, uint32_t i) { return d3(x[i], y[i], z[i]); }
+RTD void st3(double* x, double* y, double* z, uint32_t i, D3 v) {
+    x[i] = v.x;
+    y[i] = v.y;
+    z[i] = v.z;
+}
+
+// wave-level compaction: lanes with pred append `value` to out[]; one atomic per wave
+RTD void wave_append(bool pred, uint32_t value, uint32_t* out, uint32_t* counter) {
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (pred) out[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = value;
+}
+RTD void wave_count(bool pred, unsigned long long* counter) {
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    if ((int)lane == __ffsll((long long)mask) - 1) atomicAdd(counter, (unsigned long long)__popcll(mask));
+}
+
+// ------------------------------------------------------------------ generate
+// integrator.rs:357-366 + sampler.rs:606-613 + geometry.rs:177-190 (+ util.rs:105-113)
+__global__ __launch_bounds__(256) void k_generate(PathState st, rt_camera cam, ChunkDesc ck,
+                                                  const uint32_t* __restrict__ pix_list, uint32_t* active,
+                                                  uint32_t* queue, Ctl* ctl, DevStats* stats) {
+    const uint32_t total = ck.n_pixels * ck.n_samples;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot == 0) {
+        ctl->n_active[0] = total;
+        ctl->n_rays[0] = total;
+        atomicAdd(&stats->paths, (unsigned long long)total);
+        atomicAdd(&stats->r1, (unsigned long long)total);
+    }
+    if (slot >= total) return;
+    const uint32_t s_local = slot / ck.n_pixels, p_local = slot - s_local * ck.n_pixels;
+    const uint32_t pix = pix_list[ck.pixel_base + p_local];
+    const uint32_t px = pix % ck.width, py = pix / ck.width;
+    uint64_t rng = rng_init(ck.seed, (uint64_t)pix, (uint64_t)(ck.sample_base + s_local));
+    const double ox = rng_next(rng), oy = rng_next(rng);
+    (void)rng_next(rng);  // time
+    (void)rng_next(rng);  // lens.x
+    (void)rng_next(rng);  // lens.y
+    const double fx = (double)px + ox, fy = (double)py + oy;
+    const double u = fx / (double)ck.width, v = fy / (double)ck.height;
+    double dx, dy;
+    for (;;) {  // rand_in_disk
+        dx = rng_next(rng);
+        dy = rng_next(rng);
+        if (dx * dx + dy * dy < 1.0) break;
+    }
+    const D3 in_disk = d3(dx, dy, 0.0) * cam.lens_radius;
+    const D3 cu = d3(cam.u[0], cam.u[1], cam.u[2]), cv = d3(cam.v[0], cam.v[1], cam.v[2]);
+    const D3 offset = cu * in_disk.x + cv * in_disk.y;
+    const D3 origin = d3(cam.origin[0], cam.origin[1], cam.origin[2]);
+    const D3 ulc = d3(cam.upper_left_corner[0], cam.upper_left_corner[1], cam.upper_left_corner[2]);
+    const D3 ho = d3(cam.horizontal_offset[0], cam.horizontal_offset[1], cam.horizontal_offset[2]);
+    const D3 vo = d3(cam.vertical_offset[0], cam.vertical_offset[1], cam.vertical_offset[2]);
+    const D3 to = ulc + ho * u - vo * v;
+    const D3 dir = to - origin;
+    (void)rng_next(rng);  // rand_range(t0, t1)
+    st3(st.ox, st.oy, st.oz, slot, origin + offset);
+    st3(st.dx, st.dy, st.dz, slot, dir - offset);
+    st3(st.bx, st.by, st.bz, slot, white());
+    st3(st.lx, st.ly, st.lz, slot, black());
+    st.rng[slot] = rng;
+    st.flags[slot] = 0u;
+    active[slot] = slot;
+    queue[slot] = slot | (kRayExt << 30);
+}
+
+// --------------------------------------------------------------------- trace
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_trace(DevScene sc, PathState st, const uint32_t* __restrict__ queue,
+                                               Ctl* ctl, int it, DevStats* stats) {
+    const uint32_t n = ctl->n_rays[it];
+    const uint32_t lane = threadIdx.x & 63u;
+    TravCount tc{0, 0, 0};
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&ctl->head[it], 64u);
+        base = __shfl(base, 0, 64);
+        if (base >= n) break;
+        const uint32_t idx = base + lane;
+        if (idx < n) {
+            const uint32_t e = queue[idx];
+            const uint32_t slot = e & kSlotMask, kind = e >> 30;
+            D3 o = ld3(st.ox, st.oy, st.oz, slot);
+            D3 d;
+            double tmin = kSmall;
+            if (kind == kRayExt) {
+                d = ld3(st.dx, st.dy, st.dz, slot);
+            } else if (kind == kRayShadow) {  // Visibility::unoccluded, hittable.rs:25-32
+                d = ld3(st.spx, st.spy, st.spz, slot) - o;
+                o = o + d * kSmall;
+                tmin = 0.0;
+            } else {
+                d = ld3(st.pdx, st.pdy, st.pdz, slot);
+            }
+            double t;
+            const int32_t prim = closest_hit<COUNT>(sc, o, d, tmin, kInf, t, &tc);
+            if (kind == kRayExt)
+                st.hit_prim[slot] = prim;
+            else if (kind == kRayShadow)
+                st.sh_prim[slot] = prim;
+            else
+                st.pr_prim[slot] = prim;
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&stats->nodes, (unsigned long long)tc.nodes);
+        atomicAdd(&stats->tris, (unsigned long long)tc.tris);
+        atomicAdd(&stats->others, (unsigned long long)tc.others);
+    }
+}
+
+// rt_intersect_batch: the same traversal on caller rays
+__global__ __launch_bounds__(256) void k_intersect_batch(DevScene sc, const rt_ray* __restrict__ rays, uint64_t n,
+                                                         rt_hit* hits) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const rt_ray r = rays[i];
+    TravCount tc{0, 0, 0};
+    double t;
+    const int32_t prim = closest_hit<false>(sc, d3(r.origin[0], r.origin[1], r.origin[2]),
+                                            d3(r.dir[0], r.dir[1], r.dir[2]), r.tmin, r.tmax, t, &tc);
+    rt_hit h;
+    h.t = prim >= 0 ? t : kInf;
+    h.prim = prim;
+    h.reserved = 0;
+    hits[i] = h;
+}
+
+// --------------------------------------------------------------------- shade
+__global__ __launch_bounds__(256) void k_shade(DevScene sc, PathState st, Ctl* ctl, int it, uint32_t max_depth,
+                                               const uint32_t* __restrict__ active_in, uint32_t* active_out,
+                                               uint32_t* queue_out, DevStats* stats) {
+    const uint32_t n_active = ctl->n_active[it];
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    // whole wave past the end: nothing to do (wave-uniform exit keeps ballots well-formed)
+    if ((idx & ~63u) >= n_active) return;
+    const bool valid = idx < n_active;
+    uint32_t slot = 0;
+    bool emit_ext = false, emit_sh = false, emit_pr = false, keep = false, shaded = false;
+    if (valid) {
+        slot = active_in[idx];
+        const uint32_t fl = st.flags[slot];
+        D3 L = ld3(st.lx, st.ly, st.lz, slot);
+        D3 o = ld3(st.ox, st.oy, st.oz, slot);
+        // ---- fold the previous vertex's direct lighting (estimate_direct's two additions)
+        if (fl & (kHasShadow | kHasProbe)) {
+            const uint32_t light_idx = fl >> kLightShift;
+            const rt_light& lt = sc.lights[light_idx];
+            D3 ld = black();
+            if (fl & kHasShadow) {
+                if (st.sh_prim[slot] == (int32_t)lt.prim_index) ld = ld + ld3(st.ax, st.ay, st.az, slot);
+            }
+            if (fl & kHasProbe) {
+                const int32_t pp = st.pr_prim[slot];
+                if (pp >= 0) {
+                    const int32_t li = sc.prims[pp].light_index;
+                    if (li >= 0 && (uint32_t)li == light_idx) {
+                        const D3 pd = ld3(st.pdx, st.pdy, st.pdz, slot);
+                        HitRec nh;
+                        if (prim_intersects(sc, pp, o, pd, kSmall, kInf, nh)) {
+                            const D3 col = light_l(sc.lights[li], nh.n, -pd);  // new_record.le(-wi)
+                            if (!is_black(col)) ld = ld + ld3(st.qx, st.qy, st.qz, slot);
+                        }
+                    }
+                }
+            }
+            const D3 bk = ld3(st.kx, st.ky, st.kz, slot);
+            L = L + cmul(ld * (double)sc.n_lights, bk);
+        }
+        uint32_t nfl = 0;
+        if (!(fl & kFoldOnly)) {
+            // ---- the vertex found by the extension ray
+            const int32_t hp = st.hit_prim[slot];
+            D3 d = ld3(st.dx, st.dy, st.dz, slot);
+            D3 beta = ld3(st.bx, st.by, st.bz, slot);
+            uint64_t rng = st.rng[slot];
+            HitRec rec;
+            bool is_some = hp >= 0;
+            if (is_some) is_some = prim_intersects(sc, hp, o, d, kSmall, kInf, rec);
+            uint32_t bounces = fl & kBounceMask;
+            bool spec = (fl & kSpecular) != 0;
+            if (bounces == 0 || spec) {  // integrator.rs:396-411 (Q18)
+                if (is_some) {
+                    const int32_t li = sc.prims[rec.prim].light_index;
+                    if (li >= 0) L = L + cmul(light_l(sc.lights[li], rec.n, -d), beta);
+                }
+            }
+            if (is_some && bounces < max_depth) {
+                Bsdf bsdf;
+                compute_scattering(sc, rec, bsdf);
+                shaded = true;
+                bool has_sh = false, has_pr = false;
+                uint32_t light_num = 0;
+                // ---- uniform_sample_one_light / estimate_direct (integrator.rs:530-634)
+                if (sc.n_lights > 0) {
+                    const double pick = rng_next(rng);
+                    light_num = (uint32_t)(pick * (double)sc.n_lights);
+                    if (light_num > sc.n_lights - 1) light_num = sc.n_lights - 1;
+                    const double ul0 = rng_next(rng), ul1 = rng_next(rng);
+                    const double us0 = rng_next(rng), us1 = rng_next(rng);
+                    const rt_light& lt = sc.lights[light_num];
+                    const rt_primitive& lp = sc.prims[lt.prim_index];
+                    const uint32_t nsf = RT_BSDF_ALL - RT_BSDF_SPECULAR;
+                    const D3 ltcolor = d3(lt.color[0], lt.color[1], lt.color[2]);
+                    D3 sp, sn;
+                    double light_pdf;
+                    sample_area(sc, lp, ul0, ul1, sp, sn, light_pdf);  // Primitive::sample (Q9)
+                    const D3 wi_raw = sp - rec.p;
+                    if (norm2(wi_raw) == 0.0) {
+                        light_pdf = 0.0;
+                    } else {
+                        const D3 wn = normalize(wi_raw);
+                        light_pdf = light_pdf * norm2(rec.p - sp) / absd(dot(sn, -wn));
+                    }
+                    D3 wi, color;
+                    if (light_pdf == 0.0 || norm2(rec.p - sp) == 0.0) {
+                        light_pdf = 0.0;
+                        wi = black();
+                        color = ltcolor;
+                    } else {
+                        wi = normalize(sp - rec.p);
+                        color = light_l(lt, sn, -wi);
+                    }
+                    if (light_pdf > 0.0 && !is_black(color)) {
+                        const D3 f = bsdf_f(bsdf, rec.wo, wi, nsf) * absd(dot(wi, rec.sh_n));
+                        const double scattering_pdf = bsdf_pdf(bsdf, rec.wo, wi, nsf);
+                        if (!is_black(f)) {
+                            has_sh = true;
+                            const double weight = power_heuristic(1, light_pdf, 1, scattering_pdf);
+                            st3(st.ax, st.ay, st.az, slot, cmul(f, color) * (weight / light_pdf));
+                            st3(st.spx, st.spy, st.spz, slot, sp);
+                        }
+                    }
+                    {
+                        D3 f2, wi2;
+                        double spdf;
+                        uint32_t sampled;
+                        bsdf_sample_f(bsdf, rec.wo, us0, us1, nsf, rng, f2, wi2, spdf, sampled);
+                        f2 = f2 * absd(dot(wi2, rec.sh_n));
+                        if (!is_black(f2) && spdf > 0.0) {
+                            double weight = 1.0;
+                            bool go = true;
+                            if ((sampled & RT_BSDF_SPECULAR) == 0) {
+                                const double lpdf = prim_pdf(sc, lp, rec.p, wi2);  // Light::pdf_li
+                                if (lpdf == 0.0)
+                                    go = false;
+                                else
+                                    weight = power_heuristic(1, spdf, 1, lpdf);
+                            }
+                            if (go) {
+                                has_pr = true;
+                                st3(st.qx, st.qy, st.qz, slot, cmul(f2, ltcolor) * (weight / spdf));
+                                st3(st.pdx, st.pdy, st.pdz, slot, wi2);
+                            }
+                        }
+                    }
+                    if (has_sh || has_pr) st3(st.kx, st.ky, st.kz, slot, beta);
+                }
+                // ---- continuation (integrator.rs:421-442)
+                const D3 wo = -d;
+                const double u0 = rng_next(rng), u1 = rng_next(rng);
+                D3 f, wi;
+                double pdf;
+                uint32_t sflags;
+                bsdf_sample_f(bsdf, wo, u0, u1, RT_BSDF_ALL, rng, f, wi, pdf, sflags);
+                bool cont = !(is_black(f) || pdf == 0.0);
+                if (cont) {
+                    beta = cmul(beta, f) * (absd(dot(wi, rec.sh_n)) / pdf);
+                    spec = (sflags & RT_BSDF_SPECULAR) != 0;
+                    d = wi;
+                    if (bounces > 3) {
+                        const double q = rmax(0.05, 1.0 - rmax(beta.x, rmax(beta.y, beta.z)));
+                        if (rng_next(rng) < q)
+                            cont = false;
+                        else
+                            beta = beta * (1.0 / (1.0 - q));
+                    }
+                    bounces = bounces + 1;
+                }
+                emit_ext = cont;
+                emit_sh = has_sh;
+                emit_pr = has_pr;
+                keep = cont || has_sh || has_pr;
+                nfl = (bounces & kBounceMask) | (spec ? kSpecular : 0u) | (cont ? 0u : kFoldOnly) |
+                      (has_sh ? kHasShadow : 0u) | (has_pr ? kHasProbe : 0u) | (light_num << kLightShift);
+                st3(st.ox, st.oy, st.oz, slot, rec.p);  // spawn_ray: origin = hit point (Q4)
+                if (cont) {
+                    st3(st.dx, st.dy, st.dz, slot, d);
+                    st3(st.bx, st.by, st.bz, slot, beta);
+                }
+                st.rng[slot] = rng;
+            }
+        }
+        st3(st.lx, st.ly, st.lz, slot, L);
+        st.flags[slot] = nfl;
+    }
+    // ---- compaction into the next iteration's path list and ray queue
+    wave_append(keep, slot, active_out, &ctl->n_active[it + 1]);
+    wave_append(emit_ext, slot | (kRayExt << 30), queue_out, &ctl->n_rays[it + 1]);
+    wave_append(emit_sh, slot | (kRayShadow << 30), queue_out, &ctl->n_rays[it + 1]);
+    wave_append(emit_pr, slot | (kRayProbe << 30), queue_out, &ctl->n_rays[it + 1]);
+    wave_count(emit_ext, &stats->r1);
+    wave_count(emit_sh, &stats->r2);
+    wave_count(emit_pr, &stats->r3);
+    wave_count(shaded, &stats->vertices);
+}
+
+// ------------------------------------------------------------------- resolve
+// util::increment_color order: each pixel's samples are added one by one, in sample order.
+__global__ __launch_bounds__(256) void k_resolve(PathState st, ChunkDesc ck, const uint32_t* __restrict__ pix_list,
+                                                 double* rgb_sum, uint32_t* n) {
+    const uint32_t p_local = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p_local >= ck.n_pixels) return;
+    const uint32_t pix = pix_list[ck.pixel_base + p_local];
+    double r = rgb_sum[(size_t)pix * 3 + 0], g = rgb_sum[(size_t)pix * 3 + 1], b = rgb_sum[(size_t)pix * 3 + 2];
+    for (uint32_t s = 0; s < ck.n_samples; s++) {
+        const uint32_t slot = s * ck.n_pixels + p_local;
+        r += st.lx[slot];
+        g += st.ly[slot];
+        b += st.lz[slot];
+    }
+    rgb_sum[(size_t)pix * 3 + 0] = r;
+    rgb_sum[(size_t)pix * 3 + 1] = g;
+    rgb_sum[(size_t)pix * 3 + 2] = b;
+    n[pix] += ck.n_samples;
+}
+
+// util.rs:400-408, 441-471: film -> ACES approx -> gamma 2.2 -> 8 bit (next-row f1)
+__global__ __launch_bounds__(256) void k_tonemap(const double* __restrict__ rgb_sum, const uint32_t* __restrict__ n,
+                                                 uint64_t npix, uint8_t* out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const double scale = 1.0 / (double)n[i];
+    for (int c = 0; c < 3; c++) {
+        double x = rgb_sum[i * 3 + c] * scale;
+        x = x * 0.6;
+        x = clampd((x * (2.51 * x + 0.03)) / (x * (2.43 * x + 0.59) + 0.14), 0.0, 1.0);
+        double v = dm_pow(x, 1.0 / 2.2) * 256.0;
+        v = __builtin_round(v);
+        out[i * 3 + c] = (uint8_t)(v != v ? 0.0 : (v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v)));
+    }
+}
+
+}  // namespace rtd

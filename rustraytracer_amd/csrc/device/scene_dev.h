@@ -1,0 +1,81 @@
+// scene_dev.h -- HBM layout of a committed scene and of the in-flight path state.
+#pragma once
+#include <stdint.h>
+
+#include "../../../include/rt_abi.h"
+
+namespace rtd {
+
+// BVH2 "fat" node, 64 B = one quarter of a 256-B HBM burst / half an L2 line:
+// both children's boxes live in the parent so one fetch decides both descents.
+// Boxes are f32 rounded OUTWARD from the f64 primitive boxes; the f64 slab test of
+// the reference (hittable.rs:494-508) is applied to them after an exact widen,
+// which keeps the test conservative (see geom.h).
+struct DevNode {
+    float lmin[3], lmax[3];
+    float rmin[3], rmax[3];
+    int32_t left, right;  // >= 0: node index; kNoChild; else leaf: -1 - (first*8 + count-1)
+    int32_t pad0, pad1;
+};
+static_assert(sizeof(DevNode) == 64, "DevNode must be 64 bytes");
+constexpr int32_t kNoChild = INT32_MIN;
+constexpr uint32_t kLeafOther = 0x80000000u;  // leaf entry is a sphere/rect, not a triangle
+constexpr int kMaxLeafPrims = 4;
+constexpr int kMaxBvhDepth = 62;  // traversal stack holds 64 entries
+
+struct DevMesh {
+    const double* p;
+    const double* n;   // null: no vertex normals
+    const double* uv;  // null: default uvs (hittable.rs:455-460)
+    const uint32_t* ind;
+};
+
+struct DevScene {
+    const DevNode* nodes;
+    const uint32_t* leaf_prim;  // leaf order -> prim index | kLeafOther
+    const double* leaf_tri;     // leaf order -> 9 doubles p0,p1,p2 (triangles), 72 B
+    const rt_primitive* prims;  // original order (shading + sphere/rect tests)
+    const DevMesh* meshes;
+    const rt_xform* xforms;
+    const rt_material* mats;
+    const rt_texture* texs;
+    const rt_light* lights;
+    uint32_t n_prims, n_lights, n_nodes, mesh_has_uv;  // mesh_has_uv: any mesh carries uvs
+};
+
+// ----------------------------------------------------------------- path state
+// SoA over path slots.  One slot = one camera sample of the current chunk.
+// Bytes per slot: 13 vec3 * 24 = 264 (o d sp pd beta L A B bk) + 8 rng + 12 prims + 4 flags.
+struct PathState {
+    double *ox, *oy, *oz;     // ray origin = last hit point (spawn_ray: no offset)
+    double *dx, *dy, *dz;     // extension direction
+    double *spx, *spy, *spz;  // sampled light point (shadow ray target)
+    double *pdx, *pdy, *pdz;  // MIS probe direction
+    double *bx, *by, *bz;     // beta
+    double *lx, *ly, *lz;     // L
+    double *ax, *ay, *az;     // pending light-sample term  (f*Le*w/pdf)
+    double *qx, *qy, *qz;     // pending bsdf-sample term   (f*Le*w/pdf)
+    double *kx, *ky, *kz;     // beta at the vertex that produced the pending terms
+    uint64_t* rng;
+    int32_t* hit_prim;        // result of the extension ray
+    int32_t* sh_prim;         // closest prim along the shadow ray (Q13)
+    int32_t* pr_prim;         // closest prim along the probe ray
+    uint32_t* flags;
+};
+// flags
+constexpr uint32_t kBounceMask = 0xffu;
+constexpr uint32_t kSpecular = 1u << 8;
+constexpr uint32_t kFoldOnly = 1u << 9;
+constexpr uint32_t kHasShadow = 1u << 10;
+constexpr uint32_t kHasProbe = 1u << 11;
+constexpr uint32_t kLightShift = 16;
+
+// queue entry = slot | kind << 30
+constexpr uint32_t kRayExt = 0u, kRayShadow = 1u, kRayProbe = 2u;
+constexpr uint32_t kSlotMask = 0x3fffffffu;
+
+struct DevStats {
+    unsigned long long paths, r1, r2, r3, vertices, nodes, tris, others;
+};
+
+}  // namespace rtd

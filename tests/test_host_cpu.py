@@ -1,0 +1,297 @@
+"""CPU-side tests: deterministic math, host scene mirror, C-ABI surface (no GPU compute)."""
+import ctypes as C
+import math
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import rustraytracer_amd as rr
+from rustraytracer_amd import _ffi as F
+from tests import oracle_ffi as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PI = 3.14159265358979
+
+
+def _dm(fn, x, y=None):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y if y is not None else np.zeros_like(x), dtype=np.float64)
+    out = np.empty_like(x)
+    dp = C.POINTER(C.c_double)
+    O.lib().oracle_detmath(fn, x.ctypes.data_as(dp), y.ctypes.data_as(dp), x.size, out.ctypes.data_as(dp))
+    return out
+
+
+def _ulps(a, b):
+    return np.abs(a - b) / np.spacing(np.abs(b))
+
+
+def test_detmath_close_to_libm():
+    # include/rt_detmath.h pins ONE implementation; it must stay within 2 ulp of the platform libm
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-7, 7, 200000)
+    assert _ulps(_dm(0, x), np.sin(x)).max() <= 2
+    assert _ulps(_dm(1, x), np.cos(x)).max() <= 2
+    big = rng.uniform(0, 70000, 200000)  # Checkered: frequency 1e4 * u * 2*pi
+    assert _ulps(_dm(0, big), np.sin(big)).max() <= 2
+    assert _ulps(_dm(1, big), np.cos(big)).max() <= 2
+    lx = np.exp(rng.uniform(-30, 30, 200000))
+    assert _ulps(_dm(2, lx), np.log(lx)).max() <= 2
+    a = rng.uniform(-1, 1, 200000)
+    b = rng.uniform(-1, 1, 200000)
+    assert _ulps(_dm(3, a), np.arccos(a)).max() <= 2
+    assert _ulps(_dm(4, a, b), np.arctan2(a, b)).max() <= 2
+    ex = rng.uniform(-50, 50, 100000)
+    assert _ulps(_dm(5, ex), np.exp(ex)).max() <= 2
+    p = rng.uniform(0, 1, 100000)
+    assert np.abs(_dm(6, p, np.full_like(p, 1 / 2.2)) - p ** (1 / 2.2)).max() < 1e-14
+    # sqrt is IEEE-exact
+    assert np.array_equal(_dm(7, lx), np.sqrt(lx))
+
+
+def test_detmath_special_values():
+    assert _dm(0, [0.0])[0] == 0.0 and _dm(1, [0.0])[0] == 1.0
+    assert _dm(2, [1.0])[0] == 0.0
+    assert _dm(3, [1.0])[0] == 0.0 and _dm(3, [-1.0])[0] == pytest.approx(math.pi)
+    assert _dm(4, [0.0], [1.0])[0] == 0.0
+    assert _dm(4, [1.0], [0.0])[0] == pytest.approx(math.pi / 2)
+    assert _dm(4, [0.0], [-1.0])[0] == pytest.approx(math.pi)
+    assert np.isnan(_dm(3, [1.5])[0])
+    assert _dm(6, [0.0], [0.4545])[0] == 0.0 and _dm(6, [1.0], [0.4545])[0] == 1.0
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads and exports every function include/*.h declares."""
+    L = F.lib()
+    declared = set()
+    for hdr in ("rt_abi.h", "rt_host.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared |= set(re.findall(r"\b(rt_[a-z0-9_]+|rrh_[a-z0-9_]+)\s*\(", text))
+    assert declared == set(F.ABI_SYMBOLS) | set(F.HOST_SYMBOLS), declared ^ (set(F.ABI_SYMBOLS) | set(F.HOST_SYMBOLS))
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    assert L.rt_abi_version() == 1
+    # the shared object really contains gfx950 code
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", F.LIB_PATH], capture_output=True, text=True)
+    assert "gfx950" in out.stdout + out.stderr
+
+
+def test_struct_layouts_match_the_header():
+    # sizes the C side static_asserts or relies on (include/rt_abi.h)
+    assert C.sizeof(F.rt_primitive) == 120
+    assert C.sizeof(F.rt_xform) == 192
+    assert C.sizeof(F.rt_texture) == 48
+    assert C.sizeof(F.rt_material) == 56
+    assert C.sizeof(F.rt_light) == 48
+    assert C.sizeof(F.rt_camera) == 15 * 8 + 9 * 8
+    assert C.sizeof(F.rt_ray) == 64 and C.sizeof(F.rt_hit) == 16
+    assert C.sizeof(F.rt_render_cfg) == 64
+    assert C.sizeof(F.rt_stats) == 8 * 8 + 16 + 8 + 32
+
+
+def test_error_behaviour_without_compute():
+    L = F.lib()
+    assert L.rt_context_create(None, 1, None) == F.RT_ERR_INVALID_ARG
+    assert b"null" in L.rt_last_error()
+    h = C.c_void_p()
+    assert L.rt_context_create(None, 2, C.byref(h)) == F.RT_ERR_UNSUPPORTED
+    assert L.rt_scene_create(None, C.byref(h)) == F.RT_ERR_INVALID_ARG
+    assert L.rt_scene_commit(None) == F.RT_ERR_INVALID_ARG
+    with pytest.raises(rr.RtError) as ei:
+        rr.Scene("no_such_scene")
+    assert "Unknown scene" in str(ei.value)  # main.rs:355-357
+    with pytest.raises(rr.RtError):
+        rr.plastic_dragon(mesh_path="/nonexistent/dragon.obj")
+
+
+def _prims(sc):
+    d = sc.desc.contents
+    return [d.prims[i] for i in range(d.n_prims)]
+
+
+def test_cornell_box_preset_matches_scenes_rs():
+    # scenes.rs:89-197
+    sc = rr.cornell_box()
+    d = sc.desc.contents
+    assert (d.n_prims, d.n_materials, d.n_textures, d.n_lights, d.n_meshes, d.n_xforms) == (18, 4, 4, 1, 0, 2)
+    pr = _prims(sc)
+    assert [p.kind for p in pr[:6]] == [F.RT_PRIM_YZ_RECT, F.RT_PRIM_YZ_RECT, F.RT_PRIM_XZ_RECT, F.RT_PRIM_XZ_RECT,
+                                        F.RT_PRIM_XZ_RECT, F.RT_PRIM_XY_RECT]
+    assert [p.flip for p in pr[:6]] == [1, 0, 1, 0, 1, 1]
+    assert [p.mat_index for p in pr[:6]] == [2, 0, 3, 1, 1, 1]
+    assert [p.light_index for p in pr[:6]] == [-1, -1, 0, -1, -1, -1]
+    assert list(pr[2].v) == [213.0, 227.0, 343.0, 332.0, 554.9]
+    # rect AABB padded by SMALL along the normal (primitive.rs:161-164)
+    assert list(pr[2].bbox_min) == [213.0, 554.9 - 0.001, 227.0] and list(pr[2].bbox_max) == [343.0, 554.9 + 0.001, 332.0]
+    # Cube::get_sides order z0 z1 y0 y1 x0 x1 with FlipFace on the min sides (hittable.rs:788-846)
+    assert [p.kind for p in pr[6:12]] == [F.RT_PRIM_XY_RECT] * 2 + [F.RT_PRIM_XZ_RECT] * 2 + [F.RT_PRIM_YZ_RECT] * 2
+    assert [p.flip for p in pr[6:12]] == [1, 0, 1, 0, 1, 0]
+    assert all(p.xform_index == 0 for p in pr[6:12]) and all(p.xform_index == 1 for p in pr[12:18])
+    # cube1 uses second_transform = translate(130,0,65) * rotY(-18 deg)
+    xf = d.xforms[0]
+    c, s = math.cos(-18 * PI / 180), math.sin(-18 * PI / 180)
+    assert list(xf.fwd) == pytest.approx([c, 0, s, 130, 0, 1, 0, 0, -s, 0, c, 65], abs=1e-15)
+    m = np.array(xf.fwd[:]).reshape(3, 4)
+    mi = np.array(xf.inv[:]).reshape(3, 4)
+    assert np.allclose(m[:, :3] @ mi[:, :3], np.eye(3), atol=1e-15)
+    assert np.allclose(m[:, :3] @ mi[:, 3] + m[:, 3], 0, atol=1e-12)
+    lt = d.lights[0]
+    assert (lt.prim_index, lt.two_sided, list(lt.color), lt.area) == (2, 0, [15.0] * 3, 130.0 * 105.0)
+    assert list(d.textures[0].color) == [0.65, 0.05, 0.05]
+    assert d.materials[3].kind == F.RT_MAT_LIGHT and d.materials[0].kind == F.RT_MAT_MATTE
+    assert sc.name == "cornell_box.png"
+
+
+def test_camera_matches_geometry_rs():
+    # geometry.rs:133-175 for the Cornell camera: from (278,278,-800) to (278,278,0), vfov 40, focus 10
+    sc1 = rr.cornell_box(aspect_ratio=1.0)  # keep the scene alive: camera points into it
+    cam = sc1.camera.contents
+    assert list(cam.origin) == [278.0, 278.0, -800.0]
+    assert list(cam.w) == [0.0, 0.0, 1.0]
+    assert list(cam.u) == [-1.0, 0.0, 0.0]  # u = -normalize(up x w)
+    assert list(cam.v) == pytest.approx([0.0, 1.0, 0.0])
+    h = math.tan(40 * PI / 180 / 2)
+    assert cam.horizontal_offset[0] == pytest.approx(-2 * h * 10, rel=1e-14)
+    assert cam.vertical_offset[1] == pytest.approx(2 * h * 10, rel=1e-14)
+    ulc = np.array(cam.origin[:]) - np.array(cam.horizontal_offset[:]) / 2 + np.array(cam.vertical_offset[:]) / 2 + [0, 0, 10]
+    assert list(cam.upper_left_corner) == pytest.approx(list(ulc), rel=1e-14)
+    assert (cam.lens_radius, cam.t0, cam.t1) == (0.0, 0.0, 1.0)
+    # aspect ratio widens only the horizontal offset
+    sc2 = rr.cornell_box(aspect_ratio=2.0)
+    cam2 = sc2.camera.contents
+    assert cam2.horizontal_offset[0] == pytest.approx(2 * cam.horizontal_offset[0])
+    assert cam2.vertical_offset[1] == cam.vertical_offset[1]
+    # rrh_camera_new is the same constructor
+    out = F.rt_camera()
+    F.lib().rrh_camera_new(O.vec(278, 278, -800), O.vec(278, 278, 0), O.vec(0, 1, 0), 1.0, 40.0, 0.0, 10.0, 0.0, 1.0,
+                           C.byref(out))
+    assert bytes(out) == bytes(cam)
+
+
+def test_mesh_presets_and_variants():
+    sc = rr.cornell_box_statue(mesh_faces=500, variant=0)
+    d = sc.desc.contents
+    assert d.n_prims == 6 + 500 and d.n_meshes == 1
+    assert d.materials[3].kind == F.RT_MAT_MATTE  # scenes.rs:243
+    assert d.lights[0].two_sided == 1 and list(d.lights[0].color) == pytest.approx([0.97 * 25, 0.92 * 25, 0.23 * 25])
+    assert d.prims[2].flip == 0 and d.prims[2].mat_index == 0  # bare XZRect light with a matte material
+    sc_m = rr.cornell_box_statue(mesh_faces=20, variant=1)
+    assert sc_m.desc.contents.materials[3].kind == F.RT_MAT_METAL
+    # the stand-in mesh sits inside the box
+    m = d.meshes[0]
+    p = np.ctypeslib.as_array(m.p, shape=(m.n_p, 3))
+    assert p.min() > 0 and p.max() < 555
+    # triangles: bbox = min/max of the three vertices (hittable.rs:264-277), tri_ind = 3*face
+    ind = np.ctypeslib.as_array(m.ind, shape=(m.n_ind,))
+    for f in (0, 17, 499):
+        pr = d.prims[6 + f]
+        assert pr.kind == F.RT_PRIM_TRIANGLE and pr.tri_ind == 3 * f and pr.mat_index == 3
+        v = p[ind[3 * f:3 * f + 3]]
+        assert list(pr.bbox_min) == list(v.min(0)) and list(pr.bbox_max) == list(v.max(0))
+
+    sc_dr = rr.plastic_dragon(mesh_faces=300, variant=1)
+    dr = sc_dr.desc.contents  # C3: metal
+    assert dr.n_prims == 1 + 300 + 1
+    assert dr.materials[1].kind == F.RT_MAT_METAL and dr.materials[1].remap_roughness == 1
+    assert list(dr.textures[dr.materials[1].tex[0]].color) == [0.05, 0.5, 0.75]
+    assert dr.textures[2].kind == F.RT_TEX_CHECKERED and dr.textures[2].frequency == 10000.0
+    assert (dr.textures[2].even, dr.textures[2].odd) == (0, 1)
+    light = dr.prims[dr.n_prims - 1]
+    assert light.flip == 1 and light.light_index == 0 and list(light.v) == [-5, -5, 5, 5, 15]
+    assert dr.lights[0].prim_index == dr.n_prims - 1 and dr.lights[0].area == 100.0
+    sc_gl = rr.plastic_dragon(mesh_faces=20, variant=2)
+    gl = sc_gl.desc.contents.materials[1]
+    assert gl.kind == F.RT_MAT_GLASS and gl.f[2] == 1.5
+    sc_pl = rr.plastic_dragon(mesh_faces=20, variant=0)
+    pl = sc_pl.desc.contents.materials[1]
+    assert pl.kind == F.RT_MAT_PLASTIC and pl.f[0] == 0.001
+
+    sc_td = rr.two_dragons(mesh_faces=100, variant=0)
+    td = sc_td.desc.contents  # C4: both dragons
+    assert td.n_prims == 2 + 200 and td.n_meshes == 2
+    assert td.prims[1].flip == 0 and td.prims[1].light_index == 0  # bare, one-sided emitter
+    assert td.prims[2].mat_index == 2 and td.prims[2 + 100].mat_index == 3
+    assert td.materials[2].kind == F.RT_MAT_GLASS and td.materials[3].kind == F.RT_MAT_METAL
+    sc_td1 = rr.two_dragons(mesh_faces=100, variant=1)
+    assert sc_td1.desc.contents.n_prims == 2 + 100  # as committed
+
+
+def test_procedural_mesh_properties():
+    sc = rr.plastic_dragon(mesh_faces=1280)  # exactly 20*8^2: no trimming
+    m = sc.desc.contents.meshes[0]
+    assert m.n_ind == 3 * 1280 and m.n_p == 10 * 64 + 2 and m.n_n == m.n_p and m.n_uv == 0
+    p = np.ctypeslib.as_array(m.p, shape=(m.n_p, 3))
+    ind = np.ctypeslib.as_array(m.ind, shape=(m.n_ind,)).reshape(-1, 3)
+    # closed genus-0 surface: every edge is shared by exactly two faces
+    e = np.sort(np.concatenate([ind[:, [0, 1]], ind[:, [1, 2]], ind[:, [2, 0]]]), axis=1)
+    _, counts = np.unique(e, axis=0, return_counts=True)
+    assert (counts == 2).all()
+    # bbox = 10 * [-0.5,0.5]*(1,0.7,0.45) (+0.67 in y), vertices are f32 values times the scale
+    ext = p.max(0) - p.min(0)
+    assert ext == pytest.approx([10.0, 7.0, 4.5], rel=1e-6)
+    q = p[:, 0] / 10.0
+    assert np.array_equal(q.astype(np.float32).astype(np.float64), q)
+    # normals point outwards (positive dot with the face normal on average) and are scaled by the transform
+    n = np.ctypeslib.as_array(m.n, shape=(m.n_n, 3))
+    fn = np.cross(p[ind[:, 1]] - p[ind[:, 0]], p[ind[:, 2]] - p[ind[:, 0]])
+    assert (np.einsum("ij,ij->i", fn, n[ind[:, 0]]) > 0).mean() > 0.99
+    assert np.linalg.norm(n, axis=1) == pytest.approx(10.0, rel=1e-6)
+    # deterministic
+    sc2 = rr.plastic_dragon(mesh_faces=1280)
+    m2 = sc2.desc.contents.meshes[0]
+    assert np.array_equal(np.ctypeslib.as_array(m2.p, shape=(m2.n_p, 3)), p)
+    # trimmed to exactly N
+    sc3 = rr.plastic_dragon(mesh_faces=1000)
+    assert sc3.desc.contents.meshes[0].n_ind == 3000
+
+
+def test_obj_parser_tobj_semantics(tmp_path):
+    # parser.rs:8-87 / tobj: first model only, fan triangulation, negative indices, transform baked in
+    obj = tmp_path / "quad.obj"
+    obj.write_text(
+        "# quad + a second object that must be ignored\n"
+        "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\n"
+        "vn 0 0 1\n"
+        "vt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\n"
+        "o first\n"
+        "f 1/1/1 2/2/1 3/3/1 4/4/1\n"
+        "o second\n"
+        "v 5 5 5\nv 6 5 5\nv 5 6 5\n"
+        "f -3 -2 -1\n")
+    sc = rr.plastic_dragon(mesh_path=str(obj))
+    d = sc.desc.contents
+    m = d.meshes[0]
+    assert m.n_ind == 6 and m.n_p == 4 and m.n_n == 4 and m.n_uv == 4
+    assert list(np.ctypeslib.as_array(m.ind, shape=(6,))) == [0, 1, 2, 0, 2, 3]
+    p = np.ctypeslib.as_array(m.p, shape=(4, 3))
+    assert np.array_equal(p, np.array([[0, 0, 0], [10, 0, 0], [10, 10, 0], [0, 10, 0]], dtype=float))  # Similarity scale 10
+    n = np.ctypeslib.as_array(m.n, shape=(4, 3))
+    assert np.array_equal(n[0], [0, 0, 10.0])  # transform_vector, not renormalised (parser.rs:45)
+    uv = np.ctypeslib.as_array(m.uv, shape=(4, 2))
+    assert np.array_equal(uv[2], [1.0, 1.0])
+    assert d.n_prims == 1 + 2 + 1
+    # the oracle uses the mesh uvs (hittable.rs:462-466)
+    osc = O.OracleScene(sc)
+    rec = osc.prim_intersect(1, (7.5, 2.5, 5.0), (0, 0, -1.0))
+    assert rec.hit == 1 and list(rec.uv) == pytest.approx([0.75, 0.25])
+
+
+def test_resolve_rgb8_reference_formula():
+    # util.rs:400-408, 441-471 via the oracle: ACES approx on 0.6*x, gamma 1/2.2, round(.*256) saturating
+    rgb = np.array([[0.0, 0.18, 1.0], [4.0, 100.0, 0.5]], dtype=np.float64) * 2
+    n = np.array([2, 2], dtype=np.uint32)
+    out = np.zeros((2, 3), dtype=np.uint8)
+    O.lib().oracle_resolve_rgb8(rgb.ctypes.data_as(C.c_void_p), n.ctypes.data_as(C.c_void_p), 2, out.ctypes.data_as(C.c_void_p))
+
+    def ref(x):
+        x *= 0.6
+        y = min(max((x * (2.51 * x + 0.03)) / (x * (2.43 * x + 0.59) + 0.14), 0.0), 1.0)
+        return min(255, max(0, round(y ** (1 / 2.2) * 256)))
+
+    want = [[ref(v) for v in row] for row in [[0.0, 0.18, 1.0], [4.0, 100.0, 0.5]]]
+    assert out.tolist() == want
+    assert out[0, 0] == 0 and out[1, 1] == 255
