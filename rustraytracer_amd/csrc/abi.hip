@@ -42,8 +42,8 @@ struct rt_context {
     // path-state pool
     uint32_t capacity = 0;
     void* pool = nullptr;
-    PathState st{};
-    uint32_t* active[2] = {nullptr, nullptr};
+    PathState st[2] = {};
+    double* lf[3] = {nullptr, nullptr, nullptr};  // film staging: radiance of retired paths
     uint32_t* queue[2] = {nullptr, nullptr};
     Ctl* ctl = nullptr;
     DevStats* stats = nullptr;
@@ -80,32 +80,31 @@ static int ensure_ctx_capacity(rt_context* c, uint32_t cap) {
         c->pool = nullptr;
         c->capacity = 0;
     }
-    // one slab: 27 double arrays, rng, 3 int arrays, flags, 2 active lists, 2 ray queues (3 rays per path)
+    // one slab: 2 x (27 double arrays, rng, 3 result arrays, flags, orig), film staging, 2 ray queues
     const size_t n = cap;
-    const size_t bytes = n * (27 * 8 + 8 + 3 * 4 + 4 + 2 * 4 + 2 * 3 * 4) + 4096;
+    const size_t bytes = n * (2 * (27 * 8 + 8 + 3 * 4 + 4 + 4) + 3 * 8 + 2 * 3 * 4) + 4096;
     HIP_TRY(hipMalloc(&c->pool, bytes));
     char* p = (char*)c->pool;
-    auto take = [&](size_t sz) {
-        char* r = p;
-        p += (sz + 255) & ~(size_t)255;
-        return (void*)r;
-    };
-    (void)take;
-    // carve without per-array padding beyond 8-byte alignment (n is a multiple of 64)
-    double** dptrs[] = {&c->st.ox, &c->st.oy, &c->st.oz, &c->st.dx, &c->st.dy, &c->st.dz, &c->st.spx, &c->st.spy, &c->st.spz,
-                        &c->st.pdx, &c->st.pdy, &c->st.pdz, &c->st.bx, &c->st.by, &c->st.bz, &c->st.lx, &c->st.ly, &c->st.lz,
-                        &c->st.ax, &c->st.ay, &c->st.az, &c->st.qx, &c->st.qy, &c->st.qz, &c->st.kx, &c->st.ky, &c->st.kz};
-    for (auto dp : dptrs) {
-        *dp = (double*)p;
+    for (int b = 0; b < 2; b++) {
+        PathState& st = c->st[b];
+        double** dptrs[] = {&st.ox, &st.oy, &st.oz, &st.dx, &st.dy, &st.dz, &st.spx, &st.spy, &st.spz,
+                            &st.pdx, &st.pdy, &st.pdz, &st.bx, &st.by, &st.bz, &st.lx, &st.ly, &st.lz,
+                            &st.ax, &st.ay, &st.az, &st.qx, &st.qy, &st.qz, &st.kx, &st.ky, &st.kz};
+        for (auto dp : dptrs) {
+            *dp = (double*)p;
+            p += n * 8;
+        }
+        st.rng = (uint64_t*)p; p += n * 8;
+        st.hit_prim = (int32_t*)p; p += n * 4;
+        st.sh_prim = (int32_t*)p; p += n * 4;
+        st.pr_prim = (int32_t*)p; p += n * 4;
+        st.flags = (uint32_t*)p; p += n * 4;
+        st.orig = (uint32_t*)p; p += n * 4;
+    }
+    for (int a = 0; a < 3; a++) {
+        c->lf[a] = (double*)p;
         p += n * 8;
     }
-    c->st.rng = (uint64_t*)p; p += n * 8;
-    c->st.hit_prim = (int32_t*)p; p += n * 4;
-    c->st.sh_prim = (int32_t*)p; p += n * 4;
-    c->st.pr_prim = (int32_t*)p; p += n * 4;
-    c->st.flags = (uint32_t*)p; p += n * 4;
-    c->active[0] = (uint32_t*)p; p += n * 4;
-    c->active[1] = (uint32_t*)p; p += n * 4;
     c->queue[0] = (uint32_t*)p; p += n * 12;
     c->queue[1] = (uint32_t*)p; p += n * 12;
     c->capacity = cap;
@@ -452,7 +451,11 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
         HIP_TRY(hipMemcpyAsync(c->pix_list, pix.data(), NP * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         const uint32_t iters = cfg->max_depth + 1;
         const bool count_trav = (cfg->flags & RT_RENDER_COUNT_TRAVERSAL) != 0;
-        const int trace_blocks = c->num_cus * 8;
+        // persistent grid = what is resident at once (more blocks would only queue behind them)
+        int occ_t = 0, occ_c = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_t, k_trace<false>, 256, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, k_trace<true>, 256, 0));
+        const int trace_blocks = c->num_cus * std::max(1, count_trav ? occ_c : occ_t);
         size_t ev_i = 0;
         hipEvent_t ev_begin = get_event(c, ev_i++), ev_end = get_event(c, ev_i++);
         if (!ev_begin || !ev_end) return fail(RT_ERR_HIP, "hipEventCreate failed");
@@ -472,27 +475,27 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
                 const uint32_t total = npx * spc;
                 const uint32_t blocks = (total + 255) / 256;
                 HIP_TRY(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), stream));
-                hipLaunchKernelGGL(k_generate, dim3(blocks), dim3(256), 0, stream, c->st, *cam, ck, c->pix_list,
-                                   c->active[0], c->queue[0], c->ctl, c->stats);
+                hipLaunchKernelGGL(k_generate, dim3(blocks), dim3(256), 0, stream, c->st[0], *cam, ck, c->pix_list,
+                                   c->queue[0], c->ctl, c->stats);
                 for (uint32_t it = 0; it < iters; it++) {
                     hipEvent_t a = get_event(c, ev_i++), b = get_event(c, ev_i++);
                     if (!a || !b) return fail(RT_ERR_HIP, "hipEventCreate failed");
                     HIP_TRY(hipEventRecord(a, stream));
                     if (count_trav)
-                        hipLaunchKernelGGL(k_trace<true>, dim3(trace_blocks), dim3(256), 0, stream, s->dev, c->st,
-                                           c->queue[it & 1], c->ctl, (int)it, c->stats);
+                        hipLaunchKernelGGL(k_trace<true>, dim3(trace_blocks), dim3(256), 0, stream, s->dev,
+                                           c->st[it & 1], c->queue[it & 1], c->ctl, (int)it, c->stats);
                     else
-                        hipLaunchKernelGGL(k_trace<false>, dim3(trace_blocks), dim3(256), 0, stream, s->dev, c->st,
-                                           c->queue[it & 1], c->ctl, (int)it, c->stats);
+                        hipLaunchKernelGGL(k_trace<false>, dim3(trace_blocks), dim3(256), 0, stream, s->dev,
+                                           c->st[it & 1], c->queue[it & 1], c->ctl, (int)it, c->stats);
                     HIP_TRY(hipEventRecord(b, stream));
                     trace_ev.emplace_back(a, b);
                     trace_launches++;
-                    hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, stream, s->dev, c->st, c->ctl, (int)it,
-                                       cfg->max_depth, c->active[it & 1], c->active[(it + 1) & 1],
-                                       c->queue[(it + 1) & 1], c->stats);
+                    hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, stream, s->dev, c->st[it & 1],
+                                       c->st[(it + 1) & 1], c->ctl, (int)it, cfg->max_depth, c->queue[(it + 1) & 1],
+                                       c->lf[0], c->lf[1], c->lf[2], c->stats);
                 }
-                hipLaunchKernelGGL(k_resolve, dim3((npx + 255) / 256), dim3(256), 0, stream, c->st, ck, c->pix_list,
-                                   d_rgb, d_n);
+                hipLaunchKernelGGL(k_resolve, dim3((npx + 255) / 256), dim3(256), 0, stream, c->lf[0], c->lf[1], c->lf[2],
+                                   ck, c->pix_list, d_rgb, d_n);
                 HIP_TRY(hipGetLastError());
             }
         }

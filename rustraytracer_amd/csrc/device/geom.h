@@ -53,21 +53,26 @@ RTD D3 xf_vector(const double* m, D3 v) {
 
 // hittable.rs:494-508 with 1/dir hoisted per ray (same IEEE value as the per-node divide).
 // Returns pass/fail; `entry` = final tmin (the box entry parameter).
+// hmin/hmax: v_min_f64 / v_max_f64 (IEEE minNum/maxNum: the non-NaN operand wins, like f64::min).
+// They can differ from rmin/rmax only in the sign of a zero result, which the slab test never observes
+// (its outputs are only compared), so the pass/fail decision and the ordering are unchanged.
+RTD double hmin(double a, double b) { return __builtin_fmin(a, b); }
+RTD double hmax(double a, double b) { return __builtin_fmax(a, b); }
 RTD bool slab(double b0x, double b0y, double b0z, double b1x, double b1y, double b1z, D3 o, D3 inv, double tmin,
               double tmax, double& entry) {
     double v1 = (b0x - o.x) * inv.x, v2 = (b1x - o.x) * inv.x;
-    tmin = rmax(tmin, rmin(v1, v2));
-    tmax = rmin(tmax, rmax(v1, v2));
+    tmin = hmax(tmin, hmin(v1, v2));
+    tmax = hmin(tmax, hmax(v1, v2));
     if (tmax <= tmin) return false;
     v1 = (b0y - o.y) * inv.y;
     v2 = (b1y - o.y) * inv.y;
-    tmin = rmax(tmin, rmin(v1, v2));
-    tmax = rmin(tmax, rmax(v1, v2));
+    tmin = hmax(tmin, hmin(v1, v2));
+    tmax = hmin(tmax, hmax(v1, v2));
     if (tmax <= tmin) return false;
     v1 = (b0z - o.z) * inv.z;
     v2 = (b1z - o.z) * inv.z;
-    tmin = rmax(tmin, rmin(v1, v2));
-    tmax = rmin(tmax, rmax(v1, v2));
+    tmin = hmax(tmin, hmin(v1, v2));
+    tmax = hmin(tmax, hmax(v1, v2));
     if (tmax <= tmin) return false;
     entry = tmin;
     return true;
@@ -75,19 +80,39 @@ RTD bool slab(double b0x, double b0y, double b0z, double b1x, double b1y, double
 
 // ------------------------------------------------------------------ triangle
 // hittable.rs:300-362: sheared edge-function test (Q4, Q6).  tmin is ignored by the reference.
-RTD bool tri_core(D3 p0, D3 p1, D3 p2, D3 o, D3 dir, double tmax, double& t, double& b0, double& b1, double& b2) {
-    D3 p0t = p0 - o, p1t = p1 - o, p2t = p2 - o;
+// Per-ray constants of the triangle test (the reference recomputes them per triangle from the same
+// inputs, hittable.rs:313-323, so hoisting them is value-identical).
+struct TriRay {
+    int kz;
+    double s_x, s_y, s_z;
+    double dir_x, dir_y, dir_z;  // the ray direction itself (sphere / rect tests)
+};
+RTD TriRay tri_ray(D3 dir) {
+    TriRay r;
     double ax = absd(dir.x), ay = absd(dir.y), az = absd(dir.z);
-    int kz = 0;
+    r.kz = 0;
     double best = ax;
-    if (ay > best) { best = ay; kz = 1; }
-    if (az > best) { best = az; kz = 2; }
-    int kx = (kz + 1) % 3, ky = (kx + 1) % 3;
-    D3 d = d3(comp(dir, kx), comp(dir, ky), comp(dir, kz));
-    p0t = d3(comp(p0t, kx), comp(p0t, ky), comp(p0t, kz));
-    p1t = d3(comp(p1t, kx), comp(p1t, ky), comp(p1t, kz));
-    p2t = d3(comp(p2t, kx), comp(p2t, ky), comp(p2t, kz));
-    double s_x = -d.x / d.z, s_y = -d.y / d.z, s_z = 1.0 / d.z;
+    if (ay > best) { best = ay; r.kz = 1; }
+    if (az > best) { best = az; r.kz = 2; }
+    const int kx = (r.kz + 1) % 3, ky = (kx + 1) % 3;
+    D3 d = d3(comp(dir, kx), comp(dir, ky), comp(dir, r.kz));
+    r.dir_x = dir.x;
+    r.dir_y = dir.y;
+    r.dir_z = dir.z;
+    r.s_x = -d.x / d.z;
+    r.s_y = -d.y / d.z;
+    r.s_z = 1.0 / d.z;
+    return r;
+}
+RTD D3 permute(D3 v, const TriRay& r) {  // util.rs:195-201 with (kx,ky,kz) a cyclic shift of (0,1,2)
+    if (r.kz == 2) return v;
+    if (r.kz == 0) return d3(v.y, v.z, v.x);
+    return d3(v.z, v.x, v.y);
+}
+RTD bool tri_core(D3 p0, D3 p1, D3 p2, D3 o, const TriRay& tr, double tmax, double& t, double& b0, double& b1,
+                  double& b2) {
+    D3 p0t = permute(p0 - o, tr), p1t = permute(p1 - o, tr), p2t = permute(p2 - o, tr);
+    const double s_x = tr.s_x, s_y = tr.s_y, s_z = tr.s_z;
     p0t.x += s_x * p0t.z; p0t.y += s_y * p0t.z;
     p1t.x += s_x * p1t.z; p1t.y += s_y * p1t.z;
     p2t.x += s_x * p2t.z; p2t.y += s_y * p2t.z;
@@ -180,7 +205,7 @@ RTD bool tri_record(const DevScene& sc, const rt_primitive& pr, D3 o, D3 dir, do
     uint32_t i1, i2, i3;
     load_tri(sc, pr, p0, p1, p2, i1, i2, i3);
     double t, b0, b1, b2;
-    if (!tri_core(p0, p1, p2, o, dir, tmax, t, b0, b1, b2)) return false;
+    if (!tri_core(p0, p1, p2, o, tri_ray(dir), tmax, t, b0, b1, b2)) return false;
     const DevMesh& m = sc.meshes[pr.mesh_index];
     TriUv uv = tri_uvs(m, i1, i2, i3);
     D3 dpdu, dpdv;
@@ -306,7 +331,7 @@ RTD bool sphere_core(const rt_primitive& pr, D3 o, D3 dir, double tmin, double t
     return false;
 }
 // intersects.rs:216-258 (Q8)
-RTDN bool sphere_record(const rt_primitive& pr, D3 o, D3 dir, double tmin, double tmax, HitRec& h) {
+RTD bool sphere_record(const rt_primitive& pr, D3 o, D3 dir, double tmin, double tmax, HitRec& h) {
     double t;
     if (!sphere_core(pr, o, dir, tmin, tmax, t)) return false;
     D3 center = d3(pr.v[0], pr.v[1], pr.v[2]);
@@ -361,122 +386,154 @@ struct TravCount {
     uint32_t nodes, tris, others;
 };
 
-// Closest hit; ties in t go to the larger prim index (ABI tie rule).
-// Returns prim index or -1; t_out = hit parameter.
+// Traversal state of one ray, advanced one node or one leaf at a time so that a wave can
+// refill finished lanes between steps (k_trace) or simply loop to completion (closest_hit).
+struct Trav {
+    D3 o, inv;
+    TriRay trr;
+    double tmin, tmax, best_t;
+    int32_t best_prim, cur;
+    int sp;
+};
+
+RTD void trav_init(Trav& tv, const DevScene& sc, D3 o, D3 dir, double tmin, double tmax) {
+    tv.o = o;
+    tv.inv = d3(1.0 / dir.x, 1.0 / dir.y, 1.0 / dir.z);
+    tv.trr = tri_ray(dir);
+    tv.tmin = tmin;
+    tv.tmax = tmax;
+    tv.best_t = tmax;
+    tv.best_prim = -1;
+    tv.cur = 0;
+    tv.sp = 0;
+}
+
+// One step: test the two children of an internal node, or the primitives of a leaf, then pop.
+// Returns false when the traversal is finished.  Ties in t go to the larger prim index.
+template <bool COUNT>
+RTD bool trav_step(Trav& tv, const DevScene& sc, int32_t* stack_node, float* stack_t, TravCount* tc) {
+    const D3 o = tv.o, inv = tv.inv;
+    const double tmin = tv.tmin, tmax = tv.tmax;
+    const int32_t cur = tv.cur;
+    const double lim = tv.best_prim >= 0 ? tv.best_t * (1.0 + 1e-9) : tmax;
+    if (cur >= 0) {
+        const float4* np = reinterpret_cast<const float4*>(&sc.nodes[cur]);
+        const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+        if (COUNT) tc->nodes++;
+        const int32_t left = __float_as_int(n3.x), right = __float_as_int(n3.y);
+        double el = 0.0, er = 0.0;
+        const bool hl = left != kNoChild && slab((double)n0.x, (double)n0.y, (double)n0.z, (double)n0.w, (double)n1.x,
+                                                 (double)n1.y, o, inv, tmin, lim, el);
+        const bool hr = right != kNoChild && slab((double)n1.z, (double)n1.w, (double)n2.x, (double)n2.y,
+                                                  (double)n2.z, (double)n2.w, o, inv, tmin, lim, er);
+        if (hl && hr) {
+            int32_t nearc = left, farc = right;
+            double ef = er;
+            if (er < el) {
+                nearc = right;
+                farc = left;
+                ef = el;
+            }
+            stack_node[tv.sp] = farc;
+            stack_t[tv.sp] = float_lower(ef);
+            tv.sp++;
+            tv.cur = nearc;
+            return true;
+        } else if (hl) {
+            tv.cur = left;
+            return true;
+        } else if (hr) {
+            tv.cur = right;
+            return true;
+        }
+    } else {
+        // leaf: -1 - (first*8 + count-1)
+        const uint32_t code = (uint32_t)(-1 - cur);
+        const uint32_t first = code >> 3, count = (code & 7u) + 1u;
+        for (uint32_t i = 0; i < count; i++) {
+            const uint32_t e = sc.leaf_prim[first + i];
+            // the vertex slot address does not depend on `e`: issue its loads beside the id load
+            const double* tvp = sc.leaf_tri + (size_t)(first + i) * 9;
+            const double2 q0 = *reinterpret_cast<const double2*>(tvp);
+            const double2 q1 = *reinterpret_cast<const double2*>(tvp + 2);
+            const double2 q2 = *reinterpret_cast<const double2*>(tvp + 4);
+            const double2 q3 = *reinterpret_cast<const double2*>(tvp + 6);
+            const double q4 = tvp[8];
+            double t;
+            int32_t pi;
+            if (!(e & kLeafOther)) {
+                const D3 p0 = d3(q0.x, q0.y, q1.x), p1 = d3(q1.y, q2.x, q2.y), p2 = d3(q3.x, q3.y, q4);
+                if (COUNT) tc->tris++;
+                // the reference tests the leaf's own f64 box on the ORIGINAL interval (hittable.rs:625)
+                double en;
+                if (!slab(rmin(p0.x, rmin(p1.x, p2.x)), rmin(p0.y, rmin(p1.y, p2.y)), rmin(p0.z, rmin(p1.z, p2.z)),
+                          rmax(p0.x, rmax(p1.x, p2.x)), rmax(p0.y, rmax(p1.y, p2.y)), rmax(p0.z, rmax(p1.z, p2.z)), o,
+                          inv, tmin, tmax, en))
+                    continue;
+                double b0, b1, b2;
+                if (!tri_core(p0, p1, p2, o, tv.trr, tmax, t, b0, b1, b2)) continue;
+                pi = (int32_t)e;
+                if (sc.mesh_has_uv) {  // rare path: uv-degenerate rejection (hittable.rs:373-378)
+                    const rt_primitive& pr = sc.prims[pi];
+                    const DevMesh& m = sc.meshes[pr.mesh_index];
+                    if (m.uv) {
+                        TriUv uv = tri_uvs(m, m.ind[pr.tri_ind], m.ind[pr.tri_ind + 1], m.ind[pr.tri_ind + 2]);
+                        D3 du, dv;
+                        if (!tri_dpdu(p0, p1, p2, uv, du, dv)) continue;
+                    }
+                }
+            } else {
+                pi = (int32_t)(e & ~kLeafOther);
+                const rt_primitive& pr = sc.prims[pi];
+                if (COUNT) tc->others++;
+                double en;
+                if (!slab(pr.bbox_min[0], pr.bbox_min[1], pr.bbox_min[2], pr.bbox_max[0], pr.bbox_max[1],
+                          pr.bbox_max[2], o, inv, tmin, tmax, en))
+                    continue;
+                // the original direction is recovered exactly only for the hoisted constants, so the
+                // sphere / rect tests take it from the reciprocal-free copy kept by the caller
+                const D3 dir = d3(tv.trr.dir_x, tv.trr.dir_y, tv.trr.dir_z);
+                if (pr.kind == RT_PRIM_SPHERE) {
+                    if (!sphere_core(pr, o, dir, tmin, tmax, t)) continue;
+                } else {
+                    double a, b;
+                    D3 to, td;
+                    if (!rect_core(sc, pr, o, dir, tmin, tmax, t, a, b, to, td)) continue;
+                }
+            }
+            if (tv.best_prim < 0 || t < tv.best_t || (t == tv.best_t && pi > tv.best_prim)) {
+                tv.best_t = t;
+                tv.best_prim = pi;
+            }
+        }
+    }
+    // pop, skipping subtrees that now start beyond the best hit
+    const double lim2 = tv.best_prim >= 0 ? tv.best_t * (1.0 + 1e-9) : tmax;
+    while (tv.sp > 0) {
+        tv.sp--;
+        if ((double)stack_t[tv.sp] <= lim2) {
+            tv.cur = stack_node[tv.sp];
+            return true;
+        }
+    }
+    return false;
+}
+
+// Closest hit of one ray, run to completion.  Returns prim index or -1; t_out = hit parameter.
 template <bool COUNT>
 RTD int32_t closest_hit(const DevScene& sc, D3 o, D3 dir, double tmin, double tmax, double& t_out, TravCount* tc) {
-    int32_t best_prim = -1;
-    double best_t = tmax;
     if (sc.n_nodes == 0) {
         t_out = tmax;
         return -1;
     }
-    const D3 inv = d3(1.0 / dir.x, 1.0 / dir.y, 1.0 / dir.z);
     int32_t stack_node[64];
     float stack_t[64];
-    int sp = 0;
-    int32_t cur = 0;
-    for (;;) {
-        const double lim = best_prim >= 0 ? best_t * (1.0 + 1e-9) : tmax;
-        if (cur >= 0) {
-            const float4* np = reinterpret_cast<const float4*>(&sc.nodes[cur]);
-            const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-            if (COUNT) tc->nodes++;
-            const int32_t left = __float_as_int(n3.x), right = __float_as_int(n3.y);
-            double el = 0.0, er = 0.0;
-            bool hl = left != kNoChild &&
-                      slab((double)n0.x, (double)n0.y, (double)n0.z, (double)n0.w, (double)n1.x, (double)n1.y, o, inv,
-                           tmin, lim, el);
-            bool hr = right != kNoChild &&
-                      slab((double)n1.z, (double)n1.w, (double)n2.x, (double)n2.y, (double)n2.z, (double)n2.w, o, inv,
-                           tmin, lim, er);
-            if (hl && hr) {
-                int32_t nearc = left, farc = right;
-                double ef = er;
-                if (er < el) {
-                    nearc = right;
-                    farc = left;
-                    ef = el;
-                }
-                stack_node[sp] = farc;
-                stack_t[sp] = float_lower(ef);
-                sp++;
-                cur = nearc;
-                continue;
-            } else if (hl) {
-                cur = left;
-                continue;
-            } else if (hr) {
-                cur = right;
-                continue;
-            }
-        } else {
-            // leaf: -1 - (first*8 + count-1)
-            const uint32_t code = (uint32_t)(-1 - cur);
-            const uint32_t first = code >> 3, count = (code & 7u) + 1u;
-            for (uint32_t i = 0; i < count; i++) {
-                const uint32_t e = sc.leaf_prim[first + i];
-                double t;
-                int32_t pi;
-                if (!(e & kLeafOther)) {
-                    const double* tv = sc.leaf_tri + (size_t)(first + i) * 9;
-                    const D3 p0 = d3(tv[0], tv[1], tv[2]), p1 = d3(tv[3], tv[4], tv[5]), p2 = d3(tv[6], tv[7], tv[8]);
-                    if (COUNT) tc->tris++;
-                    // the reference tests the leaf's own f64 box on the ORIGINAL interval (hittable.rs:625)
-                    double en;
-                    if (!slab(rmin(p0.x, rmin(p1.x, p2.x)), rmin(p0.y, rmin(p1.y, p2.y)), rmin(p0.z, rmin(p1.z, p2.z)),
-                              rmax(p0.x, rmax(p1.x, p2.x)), rmax(p0.y, rmax(p1.y, p2.y)), rmax(p0.z, rmax(p1.z, p2.z)),
-                              o, inv, tmin, tmax, en))
-                        continue;
-                    double b0, b1, b2;
-                    if (!tri_core(p0, p1, p2, o, dir, tmax, t, b0, b1, b2)) continue;
-                    pi = (int32_t)e;
-                    if (sc.mesh_has_uv) {  // rare path: uv-degenerate rejection (hittable.rs:373-378)
-                        const rt_primitive& pr = sc.prims[pi];
-                        const DevMesh& m = sc.meshes[pr.mesh_index];
-                        if (m.uv) {
-                            TriUv uv = tri_uvs(m, m.ind[pr.tri_ind], m.ind[pr.tri_ind + 1], m.ind[pr.tri_ind + 2]);
-                            D3 du, dv;
-                            if (!tri_dpdu(p0, p1, p2, uv, du, dv)) continue;
-                        }
-                    }
-                } else {
-                    pi = (int32_t)(e & ~kLeafOther);
-                    const rt_primitive& pr = sc.prims[pi];
-                    if (COUNT) tc->others++;
-                    double en;
-                    if (!slab(pr.bbox_min[0], pr.bbox_min[1], pr.bbox_min[2], pr.bbox_max[0], pr.bbox_max[1],
-                              pr.bbox_max[2], o, inv, tmin, tmax, en))
-                        continue;
-                    if (pr.kind == RT_PRIM_SPHERE) {
-                        if (!sphere_core(pr, o, dir, tmin, tmax, t)) continue;
-                    } else {
-                        double a, b;
-                        D3 to, td;
-                        if (!rect_core(sc, pr, o, dir, tmin, tmax, t, a, b, to, td)) continue;
-                    }
-                }
-                if (best_prim < 0 || t < best_t || (t == best_t && pi > best_prim)) {
-                    best_t = t;
-                    best_prim = pi;
-                }
-            }
-        }
-        // pop, skipping subtrees that now start beyond the best hit
-        bool got = false;
-        const double lim2 = best_prim >= 0 ? best_t * (1.0 + 1e-9) : tmax;
-        while (sp > 0) {
-            sp--;
-            if ((double)stack_t[sp] <= lim2) {
-                cur = stack_node[sp];
-                got = true;
-                break;
-            }
-        }
-        if (!got) break;
+    Trav tv;
+    trav_init(tv, sc, o, dir, tmin, tmax);
+    while (trav_step<COUNT>(tv, sc, stack_node, stack_t, tc)) {
     }
-    t_out = best_t;
-    return best_prim;
+    t_out = tv.best_t;
+    return tv.best_prim;
 }
 
 }  // namespace rtd

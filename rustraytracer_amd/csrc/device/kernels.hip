@@ -12,6 +12,10 @@
 //            (integrator.rs:530-659), samples the continuation, Russian roulette
 //            (integrator.rs:375-445), then compacts survivors and their rays into the
 //            next queues with __ballot/__popcll prefix sums (one atomic per wave).
+// Path state is PHYSICALLY compacted every bounce: k_shade reads slot i of buffer X[it&1] and
+// writes survivors to consecutive slots of X[(it+1)&1], so every state access of every kernel
+// is a dense, coalesced SoA stream however few paths survive (a sparse in-place SoA costs a
+// whole 64-B HBM atom per 8-B field).  A retired path drops its radiance into lfinal[orig].
 // The R2/R3 results never influence control flow or RNG draws of the path, only
 // additions into L, which is why they can be traced one iteration late.
 // Film: k_resolve sums each pixel's samples in sample order in f64 -- the order of
@@ -54,6 +58,17 @@ RTD void wave_append(bool pred, uint32_t value, uint32_t* out, uint32_t* counter
     base = __shfl(base, leader, 64);
     if (pred) out[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = value;
 }
+// wave-level allocation: lanes with pred get consecutive indices from *counter (one atomic per wave)
+RTD uint32_t wave_alloc(bool pred, uint32_t* counter) {
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return 0u;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
 RTD void wave_count(bool pred, unsigned long long* counter) {
     const unsigned long long mask = __ballot(pred);
     if (mask == 0ull) return;
@@ -64,8 +79,8 @@ RTD void wave_count(bool pred, unsigned long long* counter) {
 // ------------------------------------------------------------------ generate
 // integrator.rs:357-366 + sampler.rs:606-613 + geometry.rs:177-190 (+ util.rs:105-113)
 __global__ __launch_bounds__(256) void k_generate(PathState st, rt_camera cam, ChunkDesc ck,
-                                                  const uint32_t* __restrict__ pix_list, uint32_t* active,
-                                                  uint32_t* queue, Ctl* ctl, DevStats* stats) {
+                                                  const uint32_t* __restrict__ pix_list, uint32_t* queue,
+                                                  Ctl* ctl, DevStats* stats) {
     const uint32_t total = ck.n_pixels * ck.n_samples;
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot == 0) {
@@ -107,46 +122,83 @@ __global__ __launch_bounds__(256) void k_generate(PathState st, rt_camera cam, C
     st3(st.lx, st.ly, st.lz, slot, black());
     st.rng[slot] = rng;
     st.flags[slot] = 0u;
-    active[slot] = slot;
+    st.orig[slot] = slot;
     queue[slot] = slot | (kRayExt << 30);
 }
 
 // --------------------------------------------------------------------- trace
+// Persistent waves with dynamic ray replacement: a lane whose ray is finished does not wait for
+// the slowest ray of its batch -- whenever kRefillLanes or more lanes of the wave are idle (or all
+// are), the idle lanes pull the next queue entries (one atomic per wave, __ballot/__popcll
+// prefix) and start them while the other lanes keep their traversal state.  Every wave leaves
+// the loop once the queue is exhausted and its own lanes are done.
+constexpr int kRefillLanes = 16;  // refill when at least this many lanes are idle
+constexpr int kStepsPerRound = 4; // traversal steps between two refill checks
+
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_trace(DevScene sc, PathState st, const uint32_t* __restrict__ queue,
                                                Ctl* ctl, int it, DevStats* stats) {
     const uint32_t n = ctl->n_rays[it];
+    // a block only joins the work-pulling loop if the queue can give it at least one batch:
+    // tail iterations with a handful of rays then cost a launch, not a grid of atomics
+    if (blockIdx.x * 256u >= n || sc.n_nodes == 0) return;
     const uint32_t lane = threadIdx.x & 63u;
     TravCount tc{0, 0, 0};
+    int32_t stack_node[64];
+    float stack_t[64];
+    Trav tv;
+    bool has_ray = false;
+    bool exhausted = false;  // wave-uniform: the queue has no more entries
+    uint32_t slot_kind = 0;
     for (;;) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&ctl->head[it], 64u);
-        base = __shfl(base, 0, 64);
-        if (base >= n) break;
-        const uint32_t idx = base + lane;
-        if (idx < n) {
-            const uint32_t e = queue[idx];
-            const uint32_t slot = e & kSlotMask, kind = e >> 30;
-            D3 o = ld3(st.ox, st.oy, st.oz, slot);
-            D3 d;
-            double tmin = kSmall;
-            if (kind == kRayExt) {
-                d = ld3(st.dx, st.dy, st.dz, slot);
-            } else if (kind == kRayShadow) {  // Visibility::unoccluded, hittable.rs:25-32
-                d = ld3(st.spx, st.spy, st.spz, slot) - o;
-                o = o + d * kSmall;
-                tmin = 0.0;
-            } else {
-                d = ld3(st.pdx, st.pdy, st.pdz, slot);
+        const unsigned long long idle = __ballot(!has_ray);
+        const int n_idle = __popcll(idle);
+        if (!exhausted && (n_idle >= kRefillLanes)) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&ctl->head[it], (uint32_t)n_idle);
+            base = __shfl(base, 0, 64);
+            if (base + (uint32_t)n_idle >= n) exhausted = true;
+            if (!has_ray) {
+                const uint32_t idx = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (idx < n) {
+                    const uint32_t e = queue[idx];
+                    const uint32_t slot = e & kSlotMask, kind = e >> 30;
+                    D3 o = ld3(st.ox, st.oy, st.oz, slot);
+                    D3 d;
+                    double tmin = kSmall;
+                    if (kind == kRayExt) {
+                        d = ld3(st.dx, st.dy, st.dz, slot);
+                    } else if (kind == kRayShadow) {  // Visibility::unoccluded, hittable.rs:25-32
+                        d = ld3(st.spx, st.spy, st.spz, slot) - o;
+                        o = o + d * kSmall;
+                        tmin = 0.0;
+                    } else {
+                        d = ld3(st.pdx, st.pdy, st.pdz, slot);
+                    }
+                    trav_init(tv, sc, o, d, tmin, kInf);
+                    slot_kind = e;
+                    has_ray = true;
+                }
             }
-            double t;
-            const int32_t prim = closest_hit<COUNT>(sc, o, d, tmin, kInf, t, &tc);
-            if (kind == kRayExt)
-                st.hit_prim[slot] = prim;
-            else if (kind == kRayShadow)
-                st.sh_prim[slot] = prim;
-            else
-                st.pr_prim[slot] = prim;
+        }
+        if (__ballot(has_ray) == 0ull) {
+            if (exhausted) break;
+            continue;  // fewer than kRefillLanes idle is impossible here (all are idle): refill again
+        }
+#pragma unroll 1
+        for (int k = 0; k < kStepsPerRound; k++) {
+            if (has_ray) {
+                if (!trav_step<COUNT>(tv, sc, stack_node, stack_t, &tc)) {
+                    const uint32_t slot = slot_kind & kSlotMask, kind = slot_kind >> 30;
+                    if (kind == kRayExt)
+                        st.hit_prim[slot] = tv.best_prim;
+                    else if (kind == kRayShadow)
+                        st.sh_prim[slot] = tv.best_prim;
+                    else
+                        st.pr_prim[slot] = tv.best_prim;
+                    has_ray = false;
+                }
+            }
         }
     }
     if (COUNT) {
@@ -174,178 +226,193 @@ __global__ __launch_bounds__(256) void k_intersect_batch(DevScene sc, const rt_r
 }
 
 // --------------------------------------------------------------------- shade
-__global__ __launch_bounds__(256) void k_shade(DevScene sc, PathState st, Ctl* ctl, int it, uint32_t max_depth,
-                                               const uint32_t* __restrict__ active_in, uint32_t* active_out,
-                                               uint32_t* queue_out, DevStats* stats) {
+__global__ __launch_bounds__(256) void k_shade(DevScene sc, PathState in, PathState out, Ctl* ctl, int it,
+                                               uint32_t max_depth, uint32_t* queue_out, double* lfx, double* lfy,
+                                               double* lfz, DevStats* stats) {
     const uint32_t n_active = ctl->n_active[it];
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     // whole wave past the end: nothing to do (wave-uniform exit keeps ballots well-formed)
-    if ((idx & ~63u) >= n_active) return;
-    const bool valid = idx < n_active;
-    uint32_t slot = 0;
+    if ((slot & ~63u) >= n_active) return;
+    const bool valid = slot < n_active;
+    const uint32_t fl = valid ? in.flags[slot] : kDead;
+    const bool live = valid && !(fl & kDead);
     bool emit_ext = false, emit_sh = false, emit_pr = false, keep = false, shaded = false;
-    if (valid) {
-        slot = active_in[idx];
-        const uint32_t fl = st.flags[slot];
-        D3 L = ld3(st.lx, st.ly, st.lz, slot);
-        D3 o = ld3(st.ox, st.oy, st.oz, slot);
+    D3 L = black(), o = black();
+    if (live) {
+        L = ld3(in.lx, in.ly, in.lz, slot);
+        o = ld3(in.ox, in.oy, in.oz, slot);
         // ---- fold the previous vertex's direct lighting (estimate_direct's two additions)
         if (fl & (kHasShadow | kHasProbe)) {
             const uint32_t light_idx = fl >> kLightShift;
             const rt_light& lt = sc.lights[light_idx];
             D3 ld = black();
             if (fl & kHasShadow) {
-                if (st.sh_prim[slot] == (int32_t)lt.prim_index) ld = ld + ld3(st.ax, st.ay, st.az, slot);
+                if (in.sh_prim[slot] == (int32_t)lt.prim_index) ld = ld + ld3(in.ax, in.ay, in.az, slot);
             }
             if (fl & kHasProbe) {
-                const int32_t pp = st.pr_prim[slot];
+                const int32_t pp = in.pr_prim[slot];
                 if (pp >= 0) {
                     const int32_t li = sc.prims[pp].light_index;
                     if (li >= 0 && (uint32_t)li == light_idx) {
-                        const D3 pd = ld3(st.pdx, st.pdy, st.pdz, slot);
+                        const D3 pd = ld3(in.pdx, in.pdy, in.pdz, slot);
                         HitRec nh;
                         if (prim_intersects(sc, pp, o, pd, kSmall, kInf, nh)) {
                             const D3 col = light_l(sc.lights[li], nh.n, -pd);  // new_record.le(-wi)
-                            if (!is_black(col)) ld = ld + ld3(st.qx, st.qy, st.qz, slot);
+                            if (!is_black(col)) ld = ld + ld3(in.qx, in.qy, in.qz, slot);
                         }
                     }
                 }
             }
-            const D3 bk = ld3(st.kx, st.ky, st.kz, slot);
+            const D3 bk = ld3(in.kx, in.ky, in.kz, slot);
             L = L + cmul(ld * (double)sc.n_lights, bk);
         }
-        uint32_t nfl = 0;
-        if (!(fl & kFoldOnly)) {
-            // ---- the vertex found by the extension ray
-            const int32_t hp = st.hit_prim[slot];
-            D3 d = ld3(st.dx, st.dy, st.dz, slot);
-            D3 beta = ld3(st.bx, st.by, st.bz, slot);
-            uint64_t rng = st.rng[slot];
-            HitRec rec;
-            bool is_some = hp >= 0;
-            if (is_some) is_some = prim_intersects(sc, hp, o, d, kSmall, kInf, rec);
-            uint32_t bounces = fl & kBounceMask;
-            bool spec = (fl & kSpecular) != 0;
-            if (bounces == 0 || spec) {  // integrator.rs:396-411 (Q18)
-                if (is_some) {
-                    const int32_t li = sc.prims[rec.prim].light_index;
-                    if (li >= 0) L = L + cmul(light_l(sc.lights[li], rec.n, -d), beta);
-                }
-            }
-            if (is_some && bounces < max_depth) {
-                Bsdf bsdf;
-                compute_scattering(sc, rec, bsdf);
-                shaded = true;
-                bool has_sh = false, has_pr = false;
-                uint32_t light_num = 0;
-                // ---- uniform_sample_one_light / estimate_direct (integrator.rs:530-634)
-                if (sc.n_lights > 0) {
-                    const double pick = rng_next(rng);
-                    light_num = (uint32_t)(pick * (double)sc.n_lights);
-                    if (light_num > sc.n_lights - 1) light_num = sc.n_lights - 1;
-                    const double ul0 = rng_next(rng), ul1 = rng_next(rng);
-                    const double us0 = rng_next(rng), us1 = rng_next(rng);
-                    const rt_light& lt = sc.lights[light_num];
-                    const rt_primitive& lp = sc.prims[lt.prim_index];
-                    const uint32_t nsf = RT_BSDF_ALL - RT_BSDF_SPECULAR;
-                    const D3 ltcolor = d3(lt.color[0], lt.color[1], lt.color[2]);
-                    D3 sp, sn;
-                    double light_pdf;
-                    sample_area(sc, lp, ul0, ul1, sp, sn, light_pdf);  // Primitive::sample (Q9)
-                    const D3 wi_raw = sp - rec.p;
-                    if (norm2(wi_raw) == 0.0) {
-                        light_pdf = 0.0;
-                    } else {
-                        const D3 wn = normalize(wi_raw);
-                        light_pdf = light_pdf * norm2(rec.p - sp) / absd(dot(sn, -wn));
-                    }
-                    D3 wi, color;
-                    if (light_pdf == 0.0 || norm2(rec.p - sp) == 0.0) {
-                        light_pdf = 0.0;
-                        wi = black();
-                        color = ltcolor;
-                    } else {
-                        wi = normalize(sp - rec.p);
-                        color = light_l(lt, sn, -wi);
-                    }
-                    if (light_pdf > 0.0 && !is_black(color)) {
-                        const D3 f = bsdf_f(bsdf, rec.wo, wi, nsf) * absd(dot(wi, rec.sh_n));
-                        const double scattering_pdf = bsdf_pdf(bsdf, rec.wo, wi, nsf);
-                        if (!is_black(f)) {
-                            has_sh = true;
-                            const double weight = power_heuristic(1, light_pdf, 1, scattering_pdf);
-                            st3(st.ax, st.ay, st.az, slot, cmul(f, color) * (weight / light_pdf));
-                            st3(st.spx, st.spy, st.spz, slot, sp);
-                        }
-                    }
-                    {
-                        D3 f2, wi2;
-                        double spdf;
-                        uint32_t sampled;
-                        bsdf_sample_f(bsdf, rec.wo, us0, us1, nsf, rng, f2, wi2, spdf, sampled);
-                        f2 = f2 * absd(dot(wi2, rec.sh_n));
-                        if (!is_black(f2) && spdf > 0.0) {
-                            double weight = 1.0;
-                            bool go = true;
-                            if ((sampled & RT_BSDF_SPECULAR) == 0) {
-                                const double lpdf = prim_pdf(sc, lp, rec.p, wi2);  // Light::pdf_li
-                                if (lpdf == 0.0)
-                                    go = false;
-                                else
-                                    weight = power_heuristic(1, spdf, 1, lpdf);
-                            }
-                            if (go) {
-                                has_pr = true;
-                                st3(st.qx, st.qy, st.qz, slot, cmul(f2, ltcolor) * (weight / spdf));
-                                st3(st.pdx, st.pdy, st.pdz, slot, wi2);
-                            }
-                        }
-                    }
-                    if (has_sh || has_pr) st3(st.kx, st.ky, st.kz, slot, beta);
-                }
-                // ---- continuation (integrator.rs:421-442)
-                const D3 wo = -d;
-                const double u0 = rng_next(rng), u1 = rng_next(rng);
-                D3 f, wi;
-                double pdf;
-                uint32_t sflags;
-                bsdf_sample_f(bsdf, wo, u0, u1, RT_BSDF_ALL, rng, f, wi, pdf, sflags);
-                bool cont = !(is_black(f) || pdf == 0.0);
-                if (cont) {
-                    beta = cmul(beta, f) * (absd(dot(wi, rec.sh_n)) / pdf);
-                    spec = (sflags & RT_BSDF_SPECULAR) != 0;
-                    d = wi;
-                    if (bounces > 3) {
-                        const double q = rmax(0.05, 1.0 - rmax(beta.x, rmax(beta.y, beta.z)));
-                        if (rng_next(rng) < q)
-                            cont = false;
-                        else
-                            beta = beta * (1.0 / (1.0 - q));
-                    }
-                    bounces = bounces + 1;
-                }
-                emit_ext = cont;
-                emit_sh = has_sh;
-                emit_pr = has_pr;
-                keep = cont || has_sh || has_pr;
-                nfl = (bounces & kBounceMask) | (spec ? kSpecular : 0u) | (cont ? 0u : kFoldOnly) |
-                      (has_sh ? kHasShadow : 0u) | (has_pr ? kHasProbe : 0u) | (light_num << kLightShift);
-                st3(st.ox, st.oy, st.oz, slot, rec.p);  // spawn_ray: origin = hit point (Q4)
-                if (cont) {
-                    st3(st.dx, st.dy, st.dz, slot, d);
-                    st3(st.bx, st.by, st.bz, slot, beta);
-                }
-                st.rng[slot] = rng;
+    }
+    // ---- the vertex found by the extension ray
+    const bool active = live && !(fl & kFoldOnly);
+    int32_t hp = -1;
+    D3 d = black(), beta = black();
+    HitRec rec;
+    bool is_some = false;
+    uint32_t bounces = fl & kBounceMask;
+    bool spec = (fl & kSpecular) != 0;
+    if (active) {
+        hp = in.hit_prim[slot];
+        d = ld3(in.dx, in.dy, in.dz, slot);
+        beta = ld3(in.bx, in.by, in.bz, slot);
+        is_some = hp >= 0;
+        if (is_some) is_some = prim_intersects(sc, hp, o, d, kSmall, kInf, rec);
+        if (bounces == 0 || spec) {  // integrator.rs:396-411 (Q18)
+            if (is_some) {
+                const int32_t li = sc.prims[rec.prim].light_index;
+                if (li >= 0) L = L + cmul(light_l(sc.lights[li], rec.n, -d), beta);
             }
         }
-        st3(st.lx, st.ly, st.lz, slot, L);
-        st.flags[slot] = nfl;
     }
-    // ---- compaction into the next iteration's path list and ray queue
-    wave_append(keep, slot, active_out, &ctl->n_active[it + 1]);
-    wave_append(emit_ext, slot | (kRayExt << 30), queue_out, &ctl->n_rays[it + 1]);
-    wave_append(emit_sh, slot | (kRayShadow << 30), queue_out, &ctl->n_rays[it + 1]);
-    wave_append(emit_pr, slot | (kRayProbe << 30), queue_out, &ctl->n_rays[it + 1]);
+    // a vertex that will be shaded gets its output slot now (dense, wave-contiguous); if the path
+    // then ends without pending light terms the slot is marked dead and skipped next bounce
+    const bool will_shade = active && is_some && bounces < max_depth;
+    const uint32_t os = wave_alloc(will_shade, &ctl->n_active[it + 1]);
+    if (will_shade) {
+        uint64_t rng = in.rng[slot];
+        Bsdf bsdf;
+        compute_scattering(sc, rec, bsdf);
+        shaded = true;
+        bool has_sh = false, has_pr = false;
+        uint32_t light_num = 0;
+        // ---- uniform_sample_one_light / estimate_direct (integrator.rs:530-634)
+        if (sc.n_lights > 0) {
+            const double pick = rng_next(rng);
+            light_num = (uint32_t)(pick * (double)sc.n_lights);
+            if (light_num > sc.n_lights - 1) light_num = sc.n_lights - 1;
+            const double ul0 = rng_next(rng), ul1 = rng_next(rng);
+            const double us0 = rng_next(rng), us1 = rng_next(rng);
+            const rt_light& lt = sc.lights[light_num];
+            const rt_primitive& lp = sc.prims[lt.prim_index];
+            const uint32_t nsf = RT_BSDF_ALL - RT_BSDF_SPECULAR;
+            const D3 ltcolor = d3(lt.color[0], lt.color[1], lt.color[2]);
+            D3 sp, sn;
+            double light_pdf;
+            sample_area(sc, lp, ul0, ul1, sp, sn, light_pdf);  // Primitive::sample (Q9)
+            const D3 wi_raw = sp - rec.p;
+            if (norm2(wi_raw) == 0.0) {
+                light_pdf = 0.0;
+            } else {
+                const D3 wn = normalize(wi_raw);
+                light_pdf = light_pdf * norm2(rec.p - sp) / absd(dot(sn, -wn));
+            }
+            D3 wi, color;
+            if (light_pdf == 0.0 || norm2(rec.p - sp) == 0.0) {
+                light_pdf = 0.0;
+                wi = black();
+                color = ltcolor;
+            } else {
+                wi = normalize(sp - rec.p);
+                color = light_l(lt, sn, -wi);
+            }
+            if (light_pdf > 0.0 && !is_black(color)) {
+                const D3 f = bsdf_f(bsdf, rec.wo, wi, nsf) * absd(dot(wi, rec.sh_n));
+                const double scattering_pdf = bsdf_pdf(bsdf, rec.wo, wi, nsf);
+                if (!is_black(f)) {
+                    has_sh = true;
+                    const double weight = power_heuristic(1, light_pdf, 1, scattering_pdf);
+                    st3(out.ax, out.ay, out.az, os, cmul(f, color) * (weight / light_pdf));
+                    st3(out.spx, out.spy, out.spz, os, sp);
+                }
+            }
+            {
+                D3 f2, wi2;
+                double spdf;
+                uint32_t sampled;
+                bsdf_sample_f(bsdf, rec.wo, us0, us1, nsf, rng, f2, wi2, spdf, sampled);
+                f2 = f2 * absd(dot(wi2, rec.sh_n));
+                if (!is_black(f2) && spdf > 0.0) {
+                    double weight = 1.0;
+                    bool go = true;
+                    if ((sampled & RT_BSDF_SPECULAR) == 0) {
+                        const double lpdf = prim_pdf(sc, lp, rec.p, wi2);  // Light::pdf_li
+                        if (lpdf == 0.0)
+                            go = false;
+                        else
+                            weight = power_heuristic(1, spdf, 1, lpdf);
+                    }
+                    if (go) {
+                        has_pr = true;
+                        st3(out.qx, out.qy, out.qz, os, cmul(f2, ltcolor) * (weight / spdf));
+                        st3(out.pdx, out.pdy, out.pdz, os, wi2);
+                    }
+                }
+            }
+            if (has_sh || has_pr) st3(out.kx, out.ky, out.kz, os, beta);
+        }
+        // ---- continuation (integrator.rs:421-442)
+        const D3 wo = -d;
+        const double u0 = rng_next(rng), u1 = rng_next(rng);
+        D3 f, wi;
+        double pdf;
+        uint32_t sflags;
+        bsdf_sample_f(bsdf, wo, u0, u1, RT_BSDF_ALL, rng, f, wi, pdf, sflags);
+        bool cont = !(is_black(f) || pdf == 0.0);
+        if (cont) {
+            beta = cmul(beta, f) * (absd(dot(wi, rec.sh_n)) / pdf);
+            spec = (sflags & RT_BSDF_SPECULAR) != 0;
+            if (bounces > 3) {
+                const double q = rmax(0.05, 1.0 - rmax(beta.x, rmax(beta.y, beta.z)));
+                if (rng_next(rng) < q)
+                    cont = false;
+                else
+                    beta = beta * (1.0 / (1.0 - q));
+            }
+            bounces = bounces + 1;
+        }
+        emit_ext = cont;
+        emit_sh = has_sh;
+        emit_pr = has_pr;
+        keep = cont || has_sh || has_pr;
+        if (keep) {
+            st3(out.ox, out.oy, out.oz, os, rec.p);  // spawn_ray: origin = hit point (Q4)
+            st3(out.lx, out.ly, out.lz, os, L);
+            if (cont) {
+                st3(out.dx, out.dy, out.dz, os, wi);
+                st3(out.bx, out.by, out.bz, os, beta);
+                out.rng[os] = rng;
+            }
+            out.orig[os] = in.orig[slot];
+            out.flags[os] = (bounces & kBounceMask) | (spec ? kSpecular : 0u) | (cont ? 0u : kFoldOnly) |
+                            (has_sh ? kHasShadow : 0u) | (has_pr ? kHasProbe : 0u) | (light_num << kLightShift);
+        } else {
+            out.flags[os] = kDead;
+        }
+    }
+    if (live && !keep) {  // retired: its radiance goes to the film staging slot of (pixel, sample)
+        const uint32_t og = in.orig[slot];
+        lfx[og] = L.x;
+        lfy[og] = L.y;
+        lfz[og] = L.z;
+    }
+    // ---- rays of the next bounce, appended wave by wave: [extension][shadow][probe]
+    wave_append(emit_ext, os | (kRayExt << 30), queue_out, &ctl->n_rays[it + 1]);
+    wave_append(emit_sh, os | (kRayShadow << 30), queue_out, &ctl->n_rays[it + 1]);
+    wave_append(emit_pr, os | (kRayProbe << 30), queue_out, &ctl->n_rays[it + 1]);
     wave_count(emit_ext, &stats->r1);
     wave_count(emit_sh, &stats->r2);
     wave_count(emit_pr, &stats->r3);
@@ -354,17 +421,18 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, PathState st, Ctl* c
 
 // ------------------------------------------------------------------- resolve
 // util::increment_color order: each pixel's samples are added one by one, in sample order.
-__global__ __launch_bounds__(256) void k_resolve(PathState st, ChunkDesc ck, const uint32_t* __restrict__ pix_list,
-                                                 double* rgb_sum, uint32_t* n) {
+__global__ __launch_bounds__(256) void k_resolve(const double* __restrict__ lfx, const double* __restrict__ lfy,
+                                                 const double* __restrict__ lfz, ChunkDesc ck,
+                                                 const uint32_t* __restrict__ pix_list, double* rgb_sum, uint32_t* n) {
     const uint32_t p_local = blockIdx.x * blockDim.x + threadIdx.x;
     if (p_local >= ck.n_pixels) return;
     const uint32_t pix = pix_list[ck.pixel_base + p_local];
     double r = rgb_sum[(size_t)pix * 3 + 0], g = rgb_sum[(size_t)pix * 3 + 1], b = rgb_sum[(size_t)pix * 3 + 2];
     for (uint32_t s = 0; s < ck.n_samples; s++) {
         const uint32_t slot = s * ck.n_pixels + p_local;
-        r += st.lx[slot];
-        g += st.ly[slot];
-        b += st.lz[slot];
+        r += lfx[slot];
+        g += lfy[slot];
+        b += lfz[slot];
     }
     rgb_sum[(size_t)pix * 3 + 0] = r;
     rgb_sum[(size_t)pix * 3 + 1] = g;

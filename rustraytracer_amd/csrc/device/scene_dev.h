@@ -45,7 +45,8 @@ struct DevScene {
 
 // ----------------------------------------------------------------- path state
 // SoA over path slots.  One slot = one camera sample of the current chunk.
-// Bytes per slot: 13 vec3 * 24 = 264 (o d sp pd beta L A B bk) + 8 rng + 12 prims + 4 flags.
+// Two such buffers ping-pong per bounce (see kernels.hip).  Bytes per slot: 9 vec3 * 24 = 216
+// (o d sp pd beta L A B bk) + 8 rng + 12 prim results + 4 flags + 4 orig = 244.
 struct PathState {
     double *ox, *oy, *oz;     // ray origin = last hit point (spawn_ray: no offset)
     double *dx, *dy, *dz;     // extension direction
@@ -61,6 +62,7 @@ struct PathState {
     int32_t* sh_prim;         // closest prim along the shadow ray (Q13)
     int32_t* pr_prim;         // closest prim along the probe ray
     uint32_t* flags;
+    uint32_t* orig;           // film staging slot of this path: sample_local * n_pixels + pixel_local
 };
 // flags
 constexpr uint32_t kBounceMask = 0xffu;
@@ -68,6 +70,7 @@ constexpr uint32_t kSpecular = 1u << 8;
 constexpr uint32_t kFoldOnly = 1u << 9;
 constexpr uint32_t kHasShadow = 1u << 10;
 constexpr uint32_t kHasProbe = 1u << 11;
+constexpr uint32_t kDead = 1u << 12;  // slot allocated for a vertex whose path then ended with nothing pending
 constexpr uint32_t kLightShift = 16;
 
 // queue entry = slot | kind << 30

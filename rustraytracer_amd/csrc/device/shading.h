@@ -294,6 +294,15 @@ RTD void bxdf_sample_f(const Lobe& l, D3 wo, double u0, double u1, uint64_t& rng
     }
 }
 
+// The lobe array is only ever indexed with compile-time constants (or through pick_lobe's
+// field-wise select) so that it lives in VGPRs; a run-time index would push it to scratch.
+RTD Lobe pick_lobe(const Bsdf& b, int i) {
+    const Lobe& a = b.lobes[0];
+    const Lobe& c = b.lobes[1];
+    if (i == 0) return a;
+    return c;
+}
+
 RTD D3 w2l(const Bsdf& b, D3 v) { return d3(dot(v, b.ss), dot(v, b.ts), dot(v, b.ns)); }
 RTD D3 l2w(const Bsdf& b, D3 v) {
     return d3(b.ss.x * v.x + b.ts.x * v.y + b.ns.x * v.z, b.ss.y * v.x + b.ts.y * v.y + b.ns.y * v.z,
@@ -301,15 +310,17 @@ RTD D3 l2w(const Bsdf& b, D3 v) {
 }
 RTD int num_components(const Bsdf& b, uint32_t flags) {
     int c = 0;
-    for (int i = 0; i < b.n; i++)
-        if (matches_flags(b.lobes[i].type, flags)) c++;
+    if (b.n > 0 && matches_flags(b.lobes[0].type, flags)) c++;
+    if (b.n > 1 && matches_flags(b.lobes[1].type, flags)) c++;
     return c;
 }
 RTD D3 bsdf_f(const Bsdf& b, D3 wow, D3 wiw, uint32_t flags) {  // bsdf.rs:83-98 (Q10)
     D3 wi = w2l(b, wiw), wo = w2l(b, wow);
     bool refl = dot(wiw, b.ng) * dot(wow, b.ng) > 0.0;
     D3 f = black();
-    for (int i = 0; i < b.n; i++) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        if (i >= b.n) break;
         const Lobe& l = b.lobes[i];
         if ((matches_flags(l.type, flags) && (refl && (l.type & RT_BSDF_REFLECTION) > 0)) ||
             (!refl && (l.type & RT_BSDF_TRANSMISSION) > 0))
@@ -324,11 +335,14 @@ RTD double bsdf_pdf(const Bsdf& b, D3 wow, D3 wiw, uint32_t flags) {  // bsdf.rs
     if (wo.z == 0.0) return 0.0;
     double pdf = 0.0;
     int matching = 0;
-    for (int i = 0; i < nc; i++)
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        if (i >= nc) break;
         if (matches_flags(b.lobes[i].type, flags)) {
             matching++;
             pdf += bxdf_pdf(b.lobes[i], wo, wi);
         }
+    }
     return matching > 0 ? pdf : 0.0;
 }
 RTD void bsdf_sample_f(const Bsdf& b, D3 wow, double u0, double u1, uint32_t type, uint64_t& rng, D3& color, D3& wiw,
@@ -342,7 +356,9 @@ RTD void bsdf_sample_f(const Bsdf& b, D3 wow, double u0, double u1, uint32_t typ
     int comp_ = (int)(uint32_t)__builtin_floor(u0 * (double)matching);
     if (comp_ > matching - 1) comp_ = matching - 1;
     int count = comp_, used = 0;
-    for (int i = 0; i < b.n; i++)
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        if (i >= b.n) break;
         if (matches_flags(b.lobes[i].type, type)) {
             if (count == 0) {
                 used = i;
@@ -350,7 +366,8 @@ RTD void bsdf_sample_f(const Bsdf& b, D3 wow, double u0, double u1, uint32_t typ
             }
             count--;
         }
-    const Lobe& l = b.lobes[used];
+    }
+    const Lobe l = pick_lobe(b, used);
     D3 wo = normalize(w2l(b, wow));
     if (wo.z == 0.0) return;
     D3 f, wi;
@@ -358,14 +375,20 @@ RTD void bsdf_sample_f(const Bsdf& b, D3 wow, double u0, double u1, uint32_t typ
     bxdf_sample_f(l, wo, u0, u1, rng, f, wi, p);
     if (p == 0.0) return;
     D3 wiw_ = l2w(b, wi);
-    if ((l.type & RT_BSDF_SPECULAR) == 0 && matching > 1)
-        for (int i = 0; i < b.n; i++)
+    if ((l.type & RT_BSDF_SPECULAR) == 0 && matching > 1) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            if (i >= b.n) break;
             if (i != used && matches_flags(b.lobes[i].type, type)) p += bxdf_pdf(b.lobes[i], wo, wi);
+        }
+    }
     if (matching > 1) p = p / (double)matching;
     if ((l.type & RT_BSDF_SPECULAR) == 0) {
         bool refl = dot(wiw_, b.ng) * dot(wow, b.ng) > 0.0;
         f = black();
-        for (int i = 0; i < b.n; i++) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            if (i >= b.n) break;
             const Lobe& li = b.lobes[i];
             if (matches_flags(li.type, type) && ((refl && (li.type & RT_BSDF_REFLECTION) > 0) ||
                                                  (!refl && (li.type & RT_BSDF_TRANSMISSION) > 0)))
@@ -418,11 +441,14 @@ RTD Lobe make_microfacet(D3 c, double ax, double ay) {  // + microfacet.rs:340-3
 RTD void compute_scattering(const DevScene& sc, const HitRec& h, Bsdf& b) {
     const rt_material& m = sc.mats[h.mat];
     b.n = 0;
+    b.lobes[0] = lobe_zero();
+    b.lobes[1] = lobe_zero();
     if (m.kind == RT_MAT_MATTE) {
         D3 color = texture_value(sc, m.tex[0], h.u, h.v);
         if (!is_black(color)) {
             bsdf_init(b, h);
-            b.lobes[b.n++] = make_lambert(color);
+            b.lobes[0] = make_lambert(color);
+            b.n = 1;
         }
     } else if (m.kind == RT_MAT_PLASTIC) {
         D3 color = texture_value(sc, m.tex[0], h.u, h.v);
@@ -430,7 +456,8 @@ RTD void compute_scattering(const DevScene& sc, const HitRec& h, Bsdf& b) {
         if (!is_black(color)) {
             bsdf_init(b, h);
             inited = true;
-            b.lobes[b.n++] = make_lambert(color);
+            b.lobes[0] = make_lambert(color);
+            b.n = 1;
         }
         D3 spec = texture_value(sc, m.tex[1], h.u, h.v);
         if (!is_black(spec)) {
@@ -441,7 +468,11 @@ RTD void compute_scattering(const DevScene& sc, const HitRec& h, Bsdf& b) {
             l.fresnel = FR_DIELECTRIC;
             l.p0 = 1.5;
             l.p1 = 1.0;
-            b.lobes[b.n++] = l;
+            if (b.n == 0)
+                b.lobes[0] = l;
+            else
+                b.lobes[1] = l;
+            b.n++;
         }
     } else if (m.kind == RT_MAT_GLASS) {
         D3 r = texture_value(sc, m.tex[0], h.u, h.v);
@@ -455,7 +486,8 @@ RTD void compute_scattering(const DevScene& sc, const HitRec& h, Bsdf& b) {
             l.t = t;
             l.p0 = m.f[2];
             l.p1 = 1.0;
-            b.lobes[b.n++] = l;
+            b.lobes[0] = l;
+            b.n = 1;
         }
     } else if (m.kind == RT_MAT_METAL) {
         bsdf_init(b, h);
@@ -467,7 +499,8 @@ RTD void compute_scattering(const DevScene& sc, const HitRec& h, Bsdf& b) {
         l.fresnel = FR_CONDUCTOR;
         l.t = texture_value(sc, m.tex[0], h.u, h.v);
         l.k = texture_value(sc, m.tex[1], h.u, h.v);
-        b.lobes[b.n++] = l;
+        b.lobes[0] = l;
+        b.n = 1;
     } else if (m.kind == RT_MAT_MIRROR) {
         bsdf_init(b, h);
         D3 color = texture_value(sc, m.tex[0], h.u, h.v);
@@ -477,7 +510,8 @@ RTD void compute_scattering(const DevScene& sc, const HitRec& h, Bsdf& b) {
             l.type = RT_BSDF_REFLECTION | RT_BSDF_SPECULAR;
             l.color = color;
             l.fresnel = FR_NOOP;
-            b.lobes[b.n++] = l;
+            b.lobes[0] = l;
+            b.n = 1;
         }
     }
     // RT_MAT_LIGHT: no lobes (material.rs:102)
