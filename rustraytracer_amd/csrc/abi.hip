@@ -5,8 +5,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -50,6 +52,10 @@ struct rt_context {
     uint32_t* pix_list = nullptr;
     size_t pix_capacity = 0;
     std::vector<hipEvent_t> events;
+    TraceTune tune{16, 4};
+    MirrorEntry* mirror_h = nullptr;  // pinned + mapped: counters published by k_trace
+    MirrorEntry* mirror_d = nullptr;
+    uint32_t chunk_seq = 0;
 };
 
 struct rt_scene {
@@ -147,6 +153,11 @@ int rt_context_create(const int* device_ids, int n_devices, rt_context** out) {
     HIP_TRY(hipGetDeviceProperties(&prop, dev));
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (const char* e = getenv("RT_TRACE_REFILL")) c->tune.refill_lanes = std::min(64, std::max(1, atoi(e)));
+    if (const char* e = getenv("RT_TRACE_STEPS")) c->tune.steps_per_round = std::max(1, atoi(e));
+    HIP_TRY(hipHostMalloc((void**)&c->mirror_h, sizeof(MirrorEntry) * 264, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(c->mirror_h, 0, sizeof(MirrorEntry) * 264);
+    HIP_TRY(hipHostGetDevicePointer((void**)&c->mirror_d, c->mirror_h, 0));
     HIP_TRY(hipMalloc((void**)&c->ctl, sizeof(Ctl)));
     HIP_TRY(hipMalloc((void**)&c->stats, sizeof(DevStats)));
     *out = c;
@@ -161,6 +172,7 @@ int rt_context_destroy(rt_context* c) {
     if (c->ctl) (void)hipFree(c->ctl);
     if (c->stats) (void)hipFree(c->stats);
     if (c->pix_list) (void)hipFree(c->pix_list);
+    if (c->mirror_h) (void)hipHostFree(c->mirror_h);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return RT_OK;
@@ -477,20 +489,47 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
                 HIP_TRY(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), stream));
                 hipLaunchKernelGGL(k_generate, dim3(blocks), dim3(256), 0, stream, c->st[0], *cam, ck, c->pix_list,
                                    c->queue[0], c->ctl, c->stats);
+                const uint32_t seq = ++c->chunk_seq;
+                uint32_t bound_active = total;  // upper bound of n_active for the iteration being launched
                 for (uint32_t it = 0; it < iters; it++) {
-                    hipEvent_t a = get_event(c, ev_i++), b = get_event(c, ev_i++);
-                    if (!a || !b) return fail(RT_ERR_HIP, "hipEventCreate failed");
-                    HIP_TRY(hipEventRecord(a, stream));
+                    if (it >= 2) {
+                        // counters published when k_trace(it-2) started; two iterations stay queued behind it
+                        volatile MirrorEntry* me = &c->mirror_h[it - 2];
+                        const auto t0 = std::chrono::steady_clock::now();
+                        uint64_t spins = 0;
+                        while (__atomic_load_n(&me->seq, __ATOMIC_ACQUIRE) != seq) {
+                            if ((++spins & 0xfff) == 0 &&
+                                std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20))
+                                return fail(RT_ERR_HIP, "device did not publish iteration %u counters within 20 s", it - 2);
+                        }
+                        bound_active = std::min(bound_active, (uint32_t)me->n_active);
+                        if (bound_active == 0) break;  // every path has retired
+                    }
+                    const uint32_t shade_blocks = (bound_active + 255) / 256;
+                    const uint32_t need_blocks = (uint32_t)std::min<uint64_t>((3ull * bound_active + 255) / 256, (uint64_t)trace_blocks);
+                    const uint32_t tblocks = std::max(1u, need_blocks);
+                    static const bool no_ev = getenv("RT_NO_TRACE_EVENTS") != nullptr;
+                    hipEvent_t a = nullptr, b = nullptr;
+                    if (!no_ev) {
+                        a = get_event(c, ev_i++);
+                        b = get_event(c, ev_i++);
+                        if (!a || !b) return fail(RT_ERR_HIP, "hipEventCreate failed");
+                        HIP_TRY(hipEventRecord(a, stream));
+                    }
                     if (count_trav)
-                        hipLaunchKernelGGL(k_trace<true>, dim3(trace_blocks), dim3(256), 0, stream, s->dev,
-                                           c->st[it & 1], c->queue[it & 1], c->ctl, (int)it, c->stats);
+                        hipLaunchKernelGGL(k_trace<true>, dim3(tblocks), dim3(256), 0, stream, s->dev,
+                                           c->st[it & 1], c->queue[it & 1], c->ctl, (int)it, c->stats, c->tune,
+                                           c->mirror_d, seq);
                     else
-                        hipLaunchKernelGGL(k_trace<false>, dim3(trace_blocks), dim3(256), 0, stream, s->dev,
-                                           c->st[it & 1], c->queue[it & 1], c->ctl, (int)it, c->stats);
-                    HIP_TRY(hipEventRecord(b, stream));
-                    trace_ev.emplace_back(a, b);
+                        hipLaunchKernelGGL(k_trace<false>, dim3(tblocks), dim3(256), 0, stream, s->dev,
+                                           c->st[it & 1], c->queue[it & 1], c->ctl, (int)it, c->stats, c->tune,
+                                           c->mirror_d, seq);
+                    if (!no_ev) {
+                        HIP_TRY(hipEventRecord(b, stream));
+                        trace_ev.emplace_back(a, b);
+                    }
                     trace_launches++;
-                    hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, stream, s->dev, c->st[it & 1],
+                    hipLaunchKernelGGL(k_shade, dim3(shade_blocks), dim3(256), 0, stream, s->dev, c->st[it & 1],
                                        c->st[(it + 1) & 1], c->ctl, (int)it, cfg->max_depth, c->queue[(it + 1) & 1],
                                        c->lf[0], c->lf[1], c->lf[2], c->stats);
                 }

@@ -386,6 +386,35 @@ struct TravCount {
     uint32_t nodes, tris, others;
 };
 
+// Per-lane traversal stack: the first kLdsStack entries live in LDS ([entry][thread] layout, one
+// 8-byte {node, entry_t} pair per lane -> conflict-free ds_read/write_b64), deeper entries spill to
+// a small private array that only keeps the node (popped unconditionally; its children are then
+// culled by their own slab tests).  Keeping the private part under ~256 B per lane matters: a larger
+// scratch frame makes every dispatch of the kernel pay a use-once scratch allocation (~0.1 ms).
+constexpr int kLdsStack = 16;
+constexpr int kOvfStack = kMaxBvhDepth + 2 - kLdsStack;
+struct TravStack {
+    int2* lds;       // &lds_stack[0][threadIdx.x], stride = blockDim.x entries
+    int lds_stride;  // threads per block
+    int32_t ovf[kOvfStack];
+};
+RTD void stack_push(TravStack& ts, int sp, int32_t node, float t) {
+    if (sp < kLdsStack)
+        ts.lds[sp * ts.lds_stride] = make_int2(node, __float_as_int(t));
+    else
+        ts.ovf[sp - kLdsStack] = node;
+}
+RTD void stack_get(const TravStack& ts, int sp, int32_t& node, float& t) {
+    if (sp < kLdsStack) {
+        const int2 v = ts.lds[sp * ts.lds_stride];
+        node = v.x;
+        t = __int_as_float(v.y);
+    } else {
+        node = ts.ovf[sp - kLdsStack];
+        t = 0.0f;
+    }
+}
+
 // Traversal state of one ray, advanced one node or one leaf at a time so that a wave can
 // refill finished lanes between steps (k_trace) or simply loop to completion (closest_hit).
 struct Trav {
@@ -411,7 +440,7 @@ RTD void trav_init(Trav& tv, const DevScene& sc, D3 o, D3 dir, double tmin, doub
 // One step: test the two children of an internal node, or the primitives of a leaf, then pop.
 // Returns false when the traversal is finished.  Ties in t go to the larger prim index.
 template <bool COUNT>
-RTD bool trav_step(Trav& tv, const DevScene& sc, int32_t* stack_node, float* stack_t, TravCount* tc) {
+RTD bool trav_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
     const D3 o = tv.o, inv = tv.inv;
     const double tmin = tv.tmin, tmax = tv.tmax;
     const int32_t cur = tv.cur;
@@ -434,8 +463,7 @@ RTD bool trav_step(Trav& tv, const DevScene& sc, int32_t* stack_node, float* sta
                 farc = left;
                 ef = el;
             }
-            stack_node[tv.sp] = farc;
-            stack_t[tv.sp] = float_lower(ef);
+            stack_push(ts, tv.sp, farc, float_lower(ef));
             tv.sp++;
             tv.cur = nearc;
             return true;
@@ -511,8 +539,11 @@ RTD bool trav_step(Trav& tv, const DevScene& sc, int32_t* stack_node, float* sta
     const double lim2 = tv.best_prim >= 0 ? tv.best_t * (1.0 + 1e-9) : tmax;
     while (tv.sp > 0) {
         tv.sp--;
-        if ((double)stack_t[tv.sp] <= lim2) {
-            tv.cur = stack_node[tv.sp];
+        int32_t node;
+        float et;
+        stack_get(ts, tv.sp, node, et);
+        if ((double)et <= lim2) {
+            tv.cur = node;
             return true;
         }
     }
@@ -521,16 +552,15 @@ RTD bool trav_step(Trav& tv, const DevScene& sc, int32_t* stack_node, float* sta
 
 // Closest hit of one ray, run to completion.  Returns prim index or -1; t_out = hit parameter.
 template <bool COUNT>
-RTD int32_t closest_hit(const DevScene& sc, D3 o, D3 dir, double tmin, double tmax, double& t_out, TravCount* tc) {
+RTD int32_t closest_hit(const DevScene& sc, D3 o, D3 dir, double tmin, double tmax, double& t_out, TravStack& ts,
+                        TravCount* tc) {
     if (sc.n_nodes == 0) {
         t_out = tmax;
         return -1;
     }
-    int32_t stack_node[64];
-    float stack_t[64];
     Trav tv;
     trav_init(tv, sc, o, dir, tmin, tmax);
-    while (trav_step<COUNT>(tv, sc, stack_node, stack_t, tc)) {
+    while (trav_step<COUNT>(tv, sc, ts, tc)) {
     }
     t_out = tv.best_t;
     return tv.best_prim;

@@ -31,6 +31,13 @@ struct Ctl {
     uint32_t head[264];
 };
 
+// Host-visible copy of the per-iteration counters (pinned, mapped memory).  k_trace(it) publishes
+// {n_active[it], n_rays[it]} when it STARTS; the host sizes the grids of iteration it+2 from it
+// (counts never grow) and stops launching once a published n_active is zero -- no stream sync.
+struct MirrorEntry {
+    uint32_t n_active, n_rays, seq, pad;
+};
+
 struct ChunkDesc {
     uint32_t n_pixels;     // pixels in this chunk (PB)
     uint32_t n_samples;    // samples per pixel in this chunk (spc)
@@ -131,21 +138,31 @@ __global__ __launch_bounds__(256) void k_generate(PathState st, rt_camera cam, C
 // the slowest ray of its batch -- whenever kRefillLanes or more lanes of the wave are idle (or all
 // are), the idle lanes pull the next queue entries (one atomic per wave, __ballot/__popcll
 // prefix) and start them while the other lanes keep their traversal state.  Every wave leaves
-// the loop once the queue is exhausted and its own lanes are done.
-constexpr int kRefillLanes = 16;  // refill when at least this many lanes are idle
-constexpr int kStepsPerRound = 4; // traversal steps between two refill checks
+// the loop once the queue is exhausted and its own lanes are done.  (tune.refill_lanes must be <= 64.)
+struct TraceTune {
+    int refill_lanes;     // refill when at least this many lanes are idle
+    int steps_per_round;  // traversal steps between two refill checks
+};
 
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_trace(DevScene sc, PathState st, const uint32_t* __restrict__ queue,
-                                               Ctl* ctl, int it, DevStats* stats) {
+                                               Ctl* ctl, int it, DevStats* stats, TraceTune tune,
+                                               MirrorEntry* mirror, uint32_t seq) {
     const uint32_t n = ctl->n_rays[it];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        mirror[it].n_active = ctl->n_active[it];
+        mirror[it].n_rays = n;
+        __hip_atomic_store(&mirror[it].seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     // a block only joins the work-pulling loop if the queue can give it at least one batch:
     // tail iterations with a handful of rays then cost a launch, not a grid of atomics
     if (blockIdx.x * 256u >= n || sc.n_nodes == 0) return;
     const uint32_t lane = threadIdx.x & 63u;
     TravCount tc{0, 0, 0};
-    int32_t stack_node[64];
-    float stack_t[64];
+    __shared__ int2 lds_stack[kLdsStack * 256];
+    TravStack ts;
+    ts.lds = &lds_stack[threadIdx.x];
+    ts.lds_stride = 256;
     Trav tv;
     bool has_ray = false;
     bool exhausted = false;  // wave-uniform: the queue has no more entries
@@ -153,7 +170,7 @@ __global__ __launch_bounds__(256) void k_trace(DevScene sc, PathState st, const 
     for (;;) {
         const unsigned long long idle = __ballot(!has_ray);
         const int n_idle = __popcll(idle);
-        if (!exhausted && (n_idle >= kRefillLanes)) {
+        if (!exhausted && (n_idle >= tune.refill_lanes)) {
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(&ctl->head[it], (uint32_t)n_idle);
             base = __shfl(base, 0, 64);
@@ -186,9 +203,9 @@ __global__ __launch_bounds__(256) void k_trace(DevScene sc, PathState st, const 
             continue;  // fewer than kRefillLanes idle is impossible here (all are idle): refill again
         }
 #pragma unroll 1
-        for (int k = 0; k < kStepsPerRound; k++) {
+        for (int k = 0; k < tune.steps_per_round; k++) {
             if (has_ray) {
-                if (!trav_step<COUNT>(tv, sc, stack_node, stack_t, &tc)) {
+                if (!trav_step<COUNT>(tv, sc, ts, &tc)) {
                     const uint32_t slot = slot_kind & kSlotMask, kind = slot_kind >> 30;
                     if (kind == kRayExt)
                         st.hit_prim[slot] = tv.best_prim;
@@ -211,13 +228,17 @@ __global__ __launch_bounds__(256) void k_trace(DevScene sc, PathState st, const 
 // rt_intersect_batch: the same traversal on caller rays
 __global__ __launch_bounds__(256) void k_intersect_batch(DevScene sc, const rt_ray* __restrict__ rays, uint64_t n,
                                                          rt_hit* hits) {
+    __shared__ int2 lds_stack[kLdsStack * 256];
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const rt_ray r = rays[i];
     TravCount tc{0, 0, 0};
+    TravStack ts;
+    ts.lds = &lds_stack[threadIdx.x];
+    ts.lds_stride = 256;
     double t;
     const int32_t prim = closest_hit<false>(sc, d3(r.origin[0], r.origin[1], r.origin[2]),
-                                            d3(r.dir[0], r.dir[1], r.dir[2]), r.tmin, r.tmax, t, &tc);
+                                            d3(r.dir[0], r.dir[1], r.dir[2]), r.tmin, r.tmax, t, ts, &tc);
     rt_hit h;
     h.t = prim >= 0 ? t : kInf;
     h.prim = prim;

@@ -21,7 +21,7 @@ static_assert(sizeof(DevNode) == 64, "DevNode must be 64 bytes");
 constexpr int32_t kNoChild = INT32_MIN;
 constexpr uint32_t kLeafOther = 0x80000000u;  // leaf entry is a sphere/rect, not a triangle
 constexpr int kMaxLeafPrims = 4;
-constexpr int kMaxBvhDepth = 62;  // traversal stack holds 64 entries
+constexpr int kMaxBvhDepth = 54;  // traversal stack: 16 LDS + 40 private entries (geom.h)
 
 struct DevMesh {
     const double* p;
