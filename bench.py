@@ -10,7 +10,7 @@ N = 1 workload: BASELINE.json configs[1] -- Cornell box + triangle-mesh statue (
 P-400k stand-in for the missing data/statue.obj), Lambertian, 512x512 @ 64 spp, max_depth 25.
 N > 1: weak scaling -- the same image at N times the samples per pixel (64*N spp), its 16x16
 tiles interleaved over the ranks (tile k -> rank k % N), so every rank keeps 512*512*64 paths;
-the per-rank films (zero outside a rank's own tiles) are reduced to rank 0 over RCCL/xGMI.
+each rank's own tiles are packed and gathered to rank 0 over RCCL/xGMI (rustraytracer_amd/dist.py).
 
 One JSON line on rank 0 with `roofline` (dominant kernel k_trace, algorithmic bytes from the
 device's traversal counters over HIP-event kernel time) and `cpu_baseline` (the oracle in
@@ -122,13 +122,14 @@ def main():
     d_rgb = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
     d_n = torch.zeros((H, W), dtype=torch.int32, device="cuda")
     cfg = rr.make_cfg(W, H, spp, seed=0, tile_rank=rank, tile_world=world, paths_in_flight=args.paths_in_flight)
+    from rustraytracer_amd import dist as rd
+    gather = rd.FilmGather(W, H, "cuda") if world > 1 else None
 
     def step():
         st = ctx.render_device(gs, scene.camera, cfg, d_rgb.data_ptr(), d_n.data_ptr())
-        if world > 1:
-            # framebuffer gather over xGMI: every rank's film is zero outside its own tiles
-            dist.reduce(d_rgb, dst=0, op=dist.ReduceOp.SUM)
-            dist.reduce(d_n, dst=0, op=dist.ReduceOp.SUM)
+        if gather is not None:
+            # the path's only exchange step: each rank's own tiles go straight to rank 0 (RCCL over xGMI)
+            gather.gather(d_rgb, d_n)
         return st
 
     def barrier():
@@ -185,7 +186,7 @@ def main():
             "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc + (f"; weak scaling: {spp} spp, 16x16 tiles interleaved over {world} ranks, "
-                                            "film reduced to rank 0 over RCCL" if world > 1 else ""),
+                                            "own tiles gathered to rank 0 over RCCL" if world > 1 else ""),
                        "width": W, "height": H, "spp": spp, "max_depth": rr.MAX_DEPTH, "seed": 0,
                        "triangles": info["n_triangles"], "bvh_nodes": info["n_bvh_nodes"],
                        "rays_per_step": rays_all / args.steps, "paths_per_step": W * H * spp,
