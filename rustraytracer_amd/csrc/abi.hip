@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -12,6 +13,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bvh_build.h"
@@ -37,25 +39,41 @@ static int fail(int code, const char* fmt, ...) {
     } while (0)
 
 // ------------------------------------------------------------------ handles
-struct rt_context {
-    int device = 0;
-    int num_cus = 256;
+// One in-flight chunk: its own stream, path-state ping-pong buffers, queues and counters.  Two
+// lanes run chunks concurrently so that one chunk's latency-bound traversal and short tail
+// launches overlap the other's ALU-heavy shading.
+struct Lane {
     hipStream_t stream = nullptr;
-    // path-state pool
     uint32_t capacity = 0;
     void* pool = nullptr;
     PathState st[2] = {};
     double* lf[3] = {nullptr, nullptr, nullptr};  // film staging: radiance of retired paths
     uint32_t* queue[2] = {nullptr, nullptr};
     Ctl* ctl = nullptr;
+    MirrorEntry* mirror_h = nullptr;  // pinned + mapped: counters published by k_trace
+    MirrorEntry* mirror_d = nullptr;
+    uint32_t chunk_seq = 0;
+    std::vector<hipEvent_t> events;
+    size_t ev_i = 0;
+    // per-render results of this lane
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_ev;
+    uint64_t trace_launches = 0;
+    int rc = RT_OK;
+    char err[512] = "";
+};
+constexpr int kLanes = 2;
+
+struct rt_context {
+    int device = 0;
+    int num_cus = 256;
+    hipStream_t stream = nullptr;
+    Lane lanes[kLanes];
+    int n_lanes = kLanes;
     DevStats* stats = nullptr;
     uint32_t* pix_list = nullptr;
     size_t pix_capacity = 0;
     std::vector<hipEvent_t> events;
-    TraceTune tune{16, 4};
-    MirrorEntry* mirror_h = nullptr;  // pinned + mapped: counters published by k_trace
-    MirrorEntry* mirror_d = nullptr;
-    uint32_t chunk_seq = 0;
+    TraceTune tune{32, 8, 4};
 };
 
 struct rt_scene {
@@ -78,21 +96,21 @@ struct rt_scene {
     rt_scene_info info{};
 };
 
-static int ensure_ctx_capacity(rt_context* c, uint32_t cap) {
-    if (c->capacity >= cap) return RT_OK;
+static int ensure_lane_capacity(rt_context* c, Lane& ln, uint32_t cap) {
+    if (ln.capacity >= cap) return RT_OK;
     HIP_TRY(hipSetDevice(c->device));
-    if (c->pool) {
-        HIP_TRY(hipFree(c->pool));
-        c->pool = nullptr;
-        c->capacity = 0;
+    if (ln.pool) {
+        HIP_TRY(hipFree(ln.pool));
+        ln.pool = nullptr;
+        ln.capacity = 0;
     }
     // one slab: 2 x (27 double arrays, rng, 3 result arrays, flags, orig), film staging, 2 ray queues
     const size_t n = cap;
     const size_t bytes = n * (2 * (27 * 8 + 8 + 3 * 4 + 4 + 4) + 3 * 8 + 2 * 3 * 4) + 4096;
-    HIP_TRY(hipMalloc(&c->pool, bytes));
-    char* p = (char*)c->pool;
+    HIP_TRY(hipMalloc(&ln.pool, bytes));
+    char* p = (char*)ln.pool;
     for (int b = 0; b < 2; b++) {
-        PathState& st = c->st[b];
+        PathState& st = ln.st[b];
         double** dptrs[] = {&st.ox, &st.oy, &st.oz, &st.dx, &st.dy, &st.dz, &st.spx, &st.spy, &st.spz,
                             &st.pdx, &st.pdy, &st.pdz, &st.bx, &st.by, &st.bz, &st.lx, &st.ly, &st.lz,
                             &st.ax, &st.ay, &st.az, &st.qx, &st.qy, &st.qz, &st.kx, &st.ky, &st.kz};
@@ -108,12 +126,12 @@ static int ensure_ctx_capacity(rt_context* c, uint32_t cap) {
         st.orig = (uint32_t*)p; p += n * 4;
     }
     for (int a = 0; a < 3; a++) {
-        c->lf[a] = (double*)p;
+        ln.lf[a] = (double*)p;
         p += n * 8;
     }
-    c->queue[0] = (uint32_t*)p; p += n * 12;
-    c->queue[1] = (uint32_t*)p; p += n * 12;
-    c->capacity = cap;
+    ln.queue[0] = (uint32_t*)p; p += n * 12;
+    ln.queue[1] = (uint32_t*)p; p += n * 12;
+    ln.capacity = cap;
     return RT_OK;
 }
 
@@ -154,11 +172,17 @@ int rt_context_create(const int* device_ids, int n_devices, rt_context** out) {
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     if (const char* e = getenv("RT_TRACE_REFILL")) c->tune.refill_lanes = std::min(64, std::max(1, atoi(e)));
-    if (const char* e = getenv("RT_TRACE_STEPS")) c->tune.steps_per_round = std::max(1, atoi(e));
-    HIP_TRY(hipHostMalloc((void**)&c->mirror_h, sizeof(MirrorEntry) * 264, hipHostMallocMapped | hipHostMallocCoherent));
-    std::memset(c->mirror_h, 0, sizeof(MirrorEntry) * 264);
-    HIP_TRY(hipHostGetDevicePointer((void**)&c->mirror_d, c->mirror_h, 0));
-    HIP_TRY(hipMalloc((void**)&c->ctl, sizeof(Ctl)));
+    if (const char* e = getenv("RT_TRACE_NODE_ROUNDS")) c->tune.node_rounds = std::max(1, atoi(e));
+    if (const char* e = getenv("RT_TRACE_LEAF_ROUNDS")) c->tune.leaf_rounds = std::max(1, atoi(e));
+    if (const char* e = getenv("RT_LANES")) c->n_lanes = std::min(kLanes, std::max(1, atoi(e)));
+    for (int i = 0; i < kLanes; i++) {
+        Lane& ln = c->lanes[i];
+        HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+        HIP_TRY(hipHostMalloc((void**)&ln.mirror_h, sizeof(MirrorEntry) * 264, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(ln.mirror_h, 0, sizeof(MirrorEntry) * 264);
+        HIP_TRY(hipHostGetDevicePointer((void**)&ln.mirror_d, ln.mirror_h, 0));
+        HIP_TRY(hipMalloc((void**)&ln.ctl, sizeof(Ctl)));
+    }
     HIP_TRY(hipMalloc((void**)&c->stats, sizeof(DevStats)));
     *out = c;
     return RT_OK;
@@ -168,11 +192,16 @@ int rt_context_destroy(rt_context* c) {
     if (!c) return RT_OK;
     (void)hipSetDevice(c->device);
     for (auto ev : c->events) (void)hipEventDestroy(ev);
-    if (c->pool) (void)hipFree(c->pool);
-    if (c->ctl) (void)hipFree(c->ctl);
+    for (int i = 0; i < kLanes; i++) {
+        Lane& ln = c->lanes[i];
+        for (auto ev : ln.events) (void)hipEventDestroy(ev);
+        if (ln.pool) (void)hipFree(ln.pool);
+        if (ln.ctl) (void)hipFree(ln.ctl);
+        if (ln.mirror_h) (void)hipHostFree(ln.mirror_h);
+        if (ln.stream) (void)hipStreamDestroy(ln.stream);
+    }
     if (c->stats) (void)hipFree(c->stats);
     if (c->pix_list) (void)hipFree(c->pix_list);
-    if (c->mirror_h) (void)hipHostFree(c->mirror_h);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return RT_OK;
@@ -394,13 +423,135 @@ static uint32_t next_pow2(uint32_t v) {  // sampler.rs:633-642
     return p;
 }
 
-static hipEvent_t get_event(rt_context* c, size_t i) {
-    while (c->events.size() <= i) {
+static hipEvent_t get_event(std::vector<hipEvent_t>& pool, size_t i) {
+    while (pool.size() <= i) {
         hipEvent_t ev;
         if (hipEventCreate(&ev) != hipSuccess) return nullptr;
-        c->events.push_back(ev);
+        pool.push_back(ev);
     }
-    return c->events[i];
+    return pool[i];
+}
+
+struct RenderJob {
+    rt_context* c;
+    rt_scene* s;
+    rt_camera cam;
+    const rt_render_cfg* cfg;
+    double* d_rgb;
+    uint32_t* d_n;
+    std::vector<ChunkDesc> chunks;
+    std::vector<hipEvent_t> resolved;  // recorded after chunk i's k_resolve
+    std::atomic<int> n_resolved{0};    // chunks whose resolve event has been recorded (host side, in order)
+    std::atomic<bool> abort{false};
+    int trace_blocks;
+    bool count_trav;
+};
+
+static int lane_fail(Lane& ln, int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ln.err, sizeof(ln.err), fmt, ap);
+    va_end(ap);
+    ln.rc = code;
+    return code;
+}
+#define LANE_TRY(expr)                                                                                      \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) {                                                                             \
+            job.abort.store(true);                                                                          \
+            return lane_fail(ln, RT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+        }                                                                                                   \
+    } while (0)
+
+// Enqueue every chunk with index == lane_id (mod n_lanes) on this lane's stream.
+static int run_lane(RenderJob& job, int lane_id, int n_lanes) {
+    rt_context* c = job.c;
+    Lane& ln = c->lanes[lane_id];
+    const rt_render_cfg* cfg = job.cfg;
+    LANE_TRY(hipSetDevice(c->device));
+    const uint32_t iters = cfg->max_depth + 1;
+    static const bool no_ev = getenv("RT_NO_TRACE_EVENTS") != nullptr;
+    for (size_t ci = (size_t)lane_id; ci < job.chunks.size(); ci += (size_t)n_lanes) {
+        if (job.abort.load()) return RT_ERR_HIP;
+        const ChunkDesc& ck = job.chunks[ci];
+        const uint32_t total = ck.n_pixels * ck.n_samples;
+        const uint32_t blocks = (total + 255) / 256;
+        hipStream_t stream = ln.stream;
+        LANE_TRY(hipMemsetAsync(ln.ctl, 0, sizeof(Ctl), stream));
+        hipLaunchKernelGGL(k_generate, dim3(blocks), dim3(256), 0, stream, ln.st[0], job.cam, ck, c->pix_list,
+                           ln.queue[0], ln.ctl, c->stats);
+        const uint32_t seq = ++ln.chunk_seq;
+        uint32_t bound_active = total;  // upper bound of n_active for the iteration being launched
+        for (uint32_t it = 0; it < iters; it++) {
+            if (it >= 2) {
+                // counters published when k_trace(it-2) started; two iterations stay queued behind it
+                volatile MirrorEntry* me = &ln.mirror_h[it - 2];
+                const auto t0 = std::chrono::steady_clock::now();
+                uint64_t spins = 0;
+                while (__atomic_load_n(&me->seq, __ATOMIC_ACQUIRE) != seq) {
+                    if ((++spins & 0xfff) == 0) {
+                        if (job.abort.load()) return RT_ERR_HIP;
+                        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
+                            job.abort.store(true);
+                            return lane_fail(ln, RT_ERR_HIP, "device did not publish iteration %u counters within 30 s", it - 2);
+                        }
+                    }
+                }
+                bound_active = std::min(bound_active, (uint32_t)me->n_active);
+                if (bound_active == 0) break;  // every path has retired
+            }
+            const uint32_t shade_blocks = (bound_active + 255) / 256;
+            const uint32_t need_blocks =
+                (uint32_t)std::min<uint64_t>((3ull * bound_active + 255) / 256, (uint64_t)job.trace_blocks);
+            const uint32_t tblocks = std::max(1u, need_blocks);
+            hipEvent_t a = nullptr, b = nullptr;
+            if (!no_ev) {
+                a = get_event(ln.events, ln.ev_i++);
+                b = get_event(ln.events, ln.ev_i++);
+                if (!a || !b) {
+                    job.abort.store(true);
+                    return lane_fail(ln, RT_ERR_HIP, "hipEventCreate failed");
+                }
+                LANE_TRY(hipEventRecord(a, stream));
+            }
+            if (job.count_trav)
+                hipLaunchKernelGGL(k_trace<true>, dim3(tblocks), dim3(256), 0, stream, job.s->dev, ln.st[it & 1],
+                                   ln.queue[it & 1], ln.ctl, (int)it, c->stats, c->tune, ln.mirror_d, seq);
+            else
+                hipLaunchKernelGGL(k_trace<false>, dim3(tblocks), dim3(256), 0, stream, job.s->dev, ln.st[it & 1],
+                                   ln.queue[it & 1], ln.ctl, (int)it, c->stats, c->tune, ln.mirror_d, seq);
+            if (!no_ev) {
+                LANE_TRY(hipEventRecord(b, stream));
+                ln.trace_ev.emplace_back(a, b);
+            }
+            ln.trace_launches++;
+            hipLaunchKernelGGL(k_shade, dim3(shade_blocks), dim3(256), 0, stream, job.s->dev, ln.st[it & 1],
+                               ln.st[(it + 1) & 1], ln.ctl, (int)it, cfg->max_depth, ln.queue[(it + 1) & 1], ln.lf[0],
+                               ln.lf[1], ln.lf[2], c->stats);
+        }
+        // film: chunks add their samples in chunk order (sample order per pixel), whatever lane ran them
+        if (ci > 0) {
+            const auto t0 = std::chrono::steady_clock::now();
+            uint64_t spins = 0;
+            while (job.n_resolved.load(std::memory_order_acquire) < (int)ci) {
+                if ((++spins & 0xfff) == 0) {
+                    if (job.abort.load()) return RT_ERR_HIP;
+                    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
+                        job.abort.store(true);
+                        return lane_fail(ln, RT_ERR_HIP, "chunk %zu never resolved", ci - 1);
+                    }
+                }
+            }
+            LANE_TRY(hipStreamWaitEvent(stream, job.resolved[ci - 1], 0));
+        }
+        hipLaunchKernelGGL(k_resolve, dim3((ck.n_pixels + 255) / 256), dim3(256), 0, stream, ln.lf[0], ln.lf[1],
+                           ln.lf[2], ck, c->pix_list, job.d_rgb, job.d_n);
+        LANE_TRY(hipGetLastError());
+        LANE_TRY(hipEventRecord(job.resolved[ci], stream));
+        job.n_resolved.store((int)ci + 1, std::memory_order_release);
+    }
+    return RT_OK;
 }
 
 static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const rt_render_cfg* cfg, double* d_rgb,
@@ -451,28 +602,13 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
             PB = P;
             spc = 1;
         }
-        const uint32_t cap = (uint32_t)((((size_t)PB * spc) + 63) & ~(size_t)63);
-        int rc = ensure_ctx_capacity(c, cap);
-        if (rc != RT_OK) return rc;
-        if (c->pix_capacity < NP) {
-            if (c->pix_list) HIP_TRY(hipFree(c->pix_list));
-            c->pix_list = nullptr;
-            HIP_TRY(hipMalloc((void**)&c->pix_list, NP * sizeof(uint32_t)));
-            c->pix_capacity = NP;
-        }
-        HIP_TRY(hipMemcpyAsync(c->pix_list, pix.data(), NP * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-        const uint32_t iters = cfg->max_depth + 1;
-        const bool count_trav = (cfg->flags & RT_RENDER_COUNT_TRAVERSAL) != 0;
-        // persistent grid = what is resident at once (more blocks would only queue behind them)
-        int occ_t = 0, occ_c = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_t, k_trace<false>, 256, 0));
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, k_trace<true>, 256, 0));
-        const int trace_blocks = c->num_cus * std::max(1, count_trav ? occ_c : occ_t);
-        size_t ev_i = 0;
-        hipEvent_t ev_begin = get_event(c, ev_i++), ev_end = get_event(c, ev_i++);
-        if (!ev_begin || !ev_end) return fail(RT_ERR_HIP, "hipEventCreate failed");
-        std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_ev;
-        HIP_TRY(hipEventRecord(ev_begin, stream));
+        RenderJob job;
+        job.c = c;
+        job.s = s;
+        job.cam = *cam;
+        job.cfg = cfg;
+        job.d_rgb = d_rgb;
+        job.d_n = d_n;
         for (size_t pb = 0; pb < NP; pb += PB) {
             const uint32_t npx = (uint32_t)std::min<size_t>(PB, NP - pb);
             for (uint32_t sb = 0; sb < spp; sb += spc) {
@@ -484,68 +620,79 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
                 ck.width = W;
                 ck.height = H;
                 ck.seed = cfg->seed;
-                const uint32_t total = npx * spc;
-                const uint32_t blocks = (total + 255) / 256;
-                HIP_TRY(hipMemsetAsync(c->ctl, 0, sizeof(Ctl), stream));
-                hipLaunchKernelGGL(k_generate, dim3(blocks), dim3(256), 0, stream, c->st[0], *cam, ck, c->pix_list,
-                                   c->queue[0], c->ctl, c->stats);
-                const uint32_t seq = ++c->chunk_seq;
-                uint32_t bound_active = total;  // upper bound of n_active for the iteration being launched
-                for (uint32_t it = 0; it < iters; it++) {
-                    if (it >= 2) {
-                        // counters published when k_trace(it-2) started; two iterations stay queued behind it
-                        volatile MirrorEntry* me = &c->mirror_h[it - 2];
-                        const auto t0 = std::chrono::steady_clock::now();
-                        uint64_t spins = 0;
-                        while (__atomic_load_n(&me->seq, __ATOMIC_ACQUIRE) != seq) {
-                            if ((++spins & 0xfff) == 0 &&
-                                std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20))
-                                return fail(RT_ERR_HIP, "device did not publish iteration %u counters within 20 s", it - 2);
-                        }
-                        bound_active = std::min(bound_active, (uint32_t)me->n_active);
-                        if (bound_active == 0) break;  // every path has retired
-                    }
-                    const uint32_t shade_blocks = (bound_active + 255) / 256;
-                    const uint32_t need_blocks = (uint32_t)std::min<uint64_t>((3ull * bound_active + 255) / 256, (uint64_t)trace_blocks);
-                    const uint32_t tblocks = std::max(1u, need_blocks);
-                    static const bool no_ev = getenv("RT_NO_TRACE_EVENTS") != nullptr;
-                    hipEvent_t a = nullptr, b = nullptr;
-                    if (!no_ev) {
-                        a = get_event(c, ev_i++);
-                        b = get_event(c, ev_i++);
-                        if (!a || !b) return fail(RT_ERR_HIP, "hipEventCreate failed");
-                        HIP_TRY(hipEventRecord(a, stream));
-                    }
-                    if (count_trav)
-                        hipLaunchKernelGGL(k_trace<true>, dim3(tblocks), dim3(256), 0, stream, s->dev,
-                                           c->st[it & 1], c->queue[it & 1], c->ctl, (int)it, c->stats, c->tune,
-                                           c->mirror_d, seq);
-                    else
-                        hipLaunchKernelGGL(k_trace<false>, dim3(tblocks), dim3(256), 0, stream, s->dev,
-                                           c->st[it & 1], c->queue[it & 1], c->ctl, (int)it, c->stats, c->tune,
-                                           c->mirror_d, seq);
-                    if (!no_ev) {
-                        HIP_TRY(hipEventRecord(b, stream));
-                        trace_ev.emplace_back(a, b);
-                    }
-                    trace_launches++;
-                    hipLaunchKernelGGL(k_shade, dim3(shade_blocks), dim3(256), 0, stream, s->dev, c->st[it & 1],
-                                       c->st[(it + 1) & 1], c->ctl, (int)it, cfg->max_depth, c->queue[(it + 1) & 1],
-                                       c->lf[0], c->lf[1], c->lf[2], c->stats);
-                }
-                hipLaunchKernelGGL(k_resolve, dim3((npx + 255) / 256), dim3(256), 0, stream, c->lf[0], c->lf[1], c->lf[2],
-                                   ck, c->pix_list, d_rgb, d_n);
-                HIP_TRY(hipGetLastError());
+                job.chunks.push_back(ck);
             }
+        }
+        const int n_lanes = (int)std::min<size_t>((size_t)c->n_lanes, job.chunks.size());
+        const uint32_t cap = (uint32_t)((((size_t)PB * spc) + 63) & ~(size_t)63);
+        for (int i = 0; i < n_lanes; i++) {
+            int rc = ensure_lane_capacity(c, c->lanes[i], cap);
+            if (rc != RT_OK) return rc;
+        }
+        if (c->pix_capacity < NP) {
+            if (c->pix_list) HIP_TRY(hipFree(c->pix_list));
+            c->pix_list = nullptr;
+            HIP_TRY(hipMalloc((void**)&c->pix_list, NP * sizeof(uint32_t)));
+            c->pix_capacity = NP;
+        }
+        HIP_TRY(hipMemcpyAsync(c->pix_list, pix.data(), NP * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        job.count_trav = (cfg->flags & RT_RENDER_COUNT_TRAVERSAL) != 0;
+        // persistent grid = what is resident at once (more blocks would only queue behind them)
+        int occ_t = 0, occ_c = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_t, k_trace<false>, 256, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, k_trace<true>, 256, 0));
+        int per_cu = std::max(1, job.count_trav ? occ_c : occ_t);
+        if (const char* e = getenv("RT_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));
+        job.trace_blocks = c->num_cus * per_cu;
+        size_t ev_i = 0;
+        hipEvent_t ev_begin = get_event(c->events, ev_i++), ev_end = get_event(c->events, ev_i++);
+        if (!ev_begin || !ev_end) return fail(RT_ERR_HIP, "hipEventCreate failed");
+        for (size_t i = 0; i < job.chunks.size(); i++) {
+            hipEvent_t e = get_event(c->events, ev_i++);
+            if (!e) return fail(RT_ERR_HIP, "hipEventCreate failed");
+            job.resolved.push_back(e);
+        }
+        HIP_TRY(hipEventRecord(ev_begin, stream));
+        for (int i = 0; i < n_lanes; i++) {
+            Lane& ln = c->lanes[i];
+            ln.ev_i = 0;
+            ln.trace_ev.clear();
+            ln.trace_launches = 0;
+            ln.rc = RT_OK;
+            ln.err[0] = 0;
+            HIP_TRY(hipStreamWaitEvent(ln.stream, ev_begin, 0));  // film / stats zeroing and pix_list upload first
+        }
+        std::vector<std::thread> workers;
+        for (int i = 1; i < n_lanes; i++) workers.emplace_back([&job, i, n_lanes] { run_lane(job, i, n_lanes); });
+        run_lane(job, 0, n_lanes);
+        for (auto& t : workers) t.join();
+        for (int i = 0; i < n_lanes; i++) {
+            Lane& ln = c->lanes[i];
+            if (ln.rc != RT_OK) {
+                (void)hipDeviceSynchronize();
+                return fail(ln.rc, "%s", ln.err);
+            }
+        }
+        // the caller's stream continues after the last chunk's film update (which follows all the others)
+        HIP_TRY(hipStreamWaitEvent(stream, job.resolved.back(), 0));
+        for (int i = 0; i < n_lanes; i++) {
+            hipEvent_t e = get_event(c->events, ev_i++);
+            if (!e) return fail(RT_ERR_HIP, "hipEventCreate failed");
+            HIP_TRY(hipEventRecord(e, c->lanes[i].stream));
+            HIP_TRY(hipStreamWaitEvent(stream, e, 0));
         }
         HIP_TRY(hipEventRecord(ev_end, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, ev_begin, ev_end));
         kernel_ms = ms;
-        for (auto& pr : trace_ev) {
-            HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
-            trace_ms += ms;
+        for (int i = 0; i < n_lanes; i++) {
+            Lane& ln = c->lanes[i];
+            for (auto& pr : ln.trace_ev) {
+                HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+                trace_ms += ms;
+            }
+            trace_launches += ln.trace_launches;
         }
     } else {
         HIP_TRY(hipStreamSynchronize(stream));

@@ -60,22 +60,21 @@ RTD double hmin(double a, double b) { return __builtin_fmin(a, b); }
 RTD double hmax(double a, double b) { return __builtin_fmax(a, b); }
 RTD bool slab(double b0x, double b0y, double b0z, double b1x, double b1y, double b1z, D3 o, D3 inv, double tmin,
               double tmax, double& entry) {
+    // The reference rejects after each axis (tmax <= tmin); tmin only grows and tmax only shrinks, so one
+    // final comparison decides the same thing without three divergent exits.
     double v1 = (b0x - o.x) * inv.x, v2 = (b1x - o.x) * inv.x;
     tmin = hmax(tmin, hmin(v1, v2));
     tmax = hmin(tmax, hmax(v1, v2));
-    if (tmax <= tmin) return false;
     v1 = (b0y - o.y) * inv.y;
     v2 = (b1y - o.y) * inv.y;
     tmin = hmax(tmin, hmin(v1, v2));
     tmax = hmin(tmax, hmax(v1, v2));
-    if (tmax <= tmin) return false;
     v1 = (b0z - o.z) * inv.z;
     v2 = (b1z - o.z) * inv.z;
     tmin = hmax(tmin, hmin(v1, v2));
     tmax = hmin(tmax, hmax(v1, v2));
-    if (tmax <= tmin) return false;
     entry = tmin;
-    return true;
+    return !(tmax <= tmin);
 }
 
 // ------------------------------------------------------------------ triangle
@@ -415,14 +414,19 @@ RTD void stack_get(const TravStack& ts, int sp, int32_t& node, float& t) {
     }
 }
 
-// Traversal state of one ray, advanced one node or one leaf at a time so that a wave can
-// refill finished lanes between steps (k_trace) or simply loop to completion (closest_hit).
+// Traversal state of one ray.  It advances in two kinds of steps so that a wave can run tight
+// node-only rounds and then primitive-only rounds (while-while traversal) and refill finished lanes
+// in between (k_trace), or simply loop to completion (closest_hit):
+//   cur >= 0            at an internal node          -> node_step()
+//   cur <  0 (not done) at a leaf, leaf_i-th primitive next -> leaf_step()
 struct Trav {
     D3 o, inv;
     TriRay trr;
     double tmin, tmax, best_t;
     int32_t best_prim, cur;
     int sp;
+    uint32_t leaf_i;
+    bool done;
 };
 
 RTD void trav_init(Trav& tv, const DevScene& sc, D3 o, D3 dir, double tmin, double tmax) {
@@ -435,108 +439,13 @@ RTD void trav_init(Trav& tv, const DevScene& sc, D3 o, D3 dir, double tmin, doub
     tv.best_prim = -1;
     tv.cur = 0;
     tv.sp = 0;
+    tv.leaf_i = 0;
+    tv.done = false;
 }
 
-// One step: test the two children of an internal node, or the primitives of a leaf, then pop.
-// Returns false when the traversal is finished.  Ties in t go to the larger prim index.
-template <bool COUNT>
-RTD bool trav_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
-    const D3 o = tv.o, inv = tv.inv;
-    const double tmin = tv.tmin, tmax = tv.tmax;
-    const int32_t cur = tv.cur;
-    const double lim = tv.best_prim >= 0 ? tv.best_t * (1.0 + 1e-9) : tmax;
-    if (cur >= 0) {
-        const float4* np = reinterpret_cast<const float4*>(&sc.nodes[cur]);
-        const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-        if (COUNT) tc->nodes++;
-        const int32_t left = __float_as_int(n3.x), right = __float_as_int(n3.y);
-        double el = 0.0, er = 0.0;
-        const bool hl = left != kNoChild && slab((double)n0.x, (double)n0.y, (double)n0.z, (double)n0.w, (double)n1.x,
-                                                 (double)n1.y, o, inv, tmin, lim, el);
-        const bool hr = right != kNoChild && slab((double)n1.z, (double)n1.w, (double)n2.x, (double)n2.y,
-                                                  (double)n2.z, (double)n2.w, o, inv, tmin, lim, er);
-        if (hl && hr) {
-            int32_t nearc = left, farc = right;
-            double ef = er;
-            if (er < el) {
-                nearc = right;
-                farc = left;
-                ef = el;
-            }
-            stack_push(ts, tv.sp, farc, float_lower(ef));
-            tv.sp++;
-            tv.cur = nearc;
-            return true;
-        } else if (hl) {
-            tv.cur = left;
-            return true;
-        } else if (hr) {
-            tv.cur = right;
-            return true;
-        }
-    } else {
-        // leaf: -1 - (first*8 + count-1)
-        const uint32_t code = (uint32_t)(-1 - cur);
-        const uint32_t first = code >> 3, count = (code & 7u) + 1u;
-        for (uint32_t i = 0; i < count; i++) {
-            const uint32_t e = sc.leaf_prim[first + i];
-            // the vertex slot address does not depend on `e`: issue its loads beside the id load
-            const double* tvp = sc.leaf_tri + (size_t)(first + i) * 9;
-            const double2 q0 = *reinterpret_cast<const double2*>(tvp);
-            const double2 q1 = *reinterpret_cast<const double2*>(tvp + 2);
-            const double2 q2 = *reinterpret_cast<const double2*>(tvp + 4);
-            const double2 q3 = *reinterpret_cast<const double2*>(tvp + 6);
-            const double q4 = tvp[8];
-            double t;
-            int32_t pi;
-            if (!(e & kLeafOther)) {
-                const D3 p0 = d3(q0.x, q0.y, q1.x), p1 = d3(q1.y, q2.x, q2.y), p2 = d3(q3.x, q3.y, q4);
-                if (COUNT) tc->tris++;
-                // the reference tests the leaf's own f64 box on the ORIGINAL interval (hittable.rs:625)
-                double en;
-                if (!slab(rmin(p0.x, rmin(p1.x, p2.x)), rmin(p0.y, rmin(p1.y, p2.y)), rmin(p0.z, rmin(p1.z, p2.z)),
-                          rmax(p0.x, rmax(p1.x, p2.x)), rmax(p0.y, rmax(p1.y, p2.y)), rmax(p0.z, rmax(p1.z, p2.z)), o,
-                          inv, tmin, tmax, en))
-                    continue;
-                double b0, b1, b2;
-                if (!tri_core(p0, p1, p2, o, tv.trr, tmax, t, b0, b1, b2)) continue;
-                pi = (int32_t)e;
-                if (sc.mesh_has_uv) {  // rare path: uv-degenerate rejection (hittable.rs:373-378)
-                    const rt_primitive& pr = sc.prims[pi];
-                    const DevMesh& m = sc.meshes[pr.mesh_index];
-                    if (m.uv) {
-                        TriUv uv = tri_uvs(m, m.ind[pr.tri_ind], m.ind[pr.tri_ind + 1], m.ind[pr.tri_ind + 2]);
-                        D3 du, dv;
-                        if (!tri_dpdu(p0, p1, p2, uv, du, dv)) continue;
-                    }
-                }
-            } else {
-                pi = (int32_t)(e & ~kLeafOther);
-                const rt_primitive& pr = sc.prims[pi];
-                if (COUNT) tc->others++;
-                double en;
-                if (!slab(pr.bbox_min[0], pr.bbox_min[1], pr.bbox_min[2], pr.bbox_max[0], pr.bbox_max[1],
-                          pr.bbox_max[2], o, inv, tmin, tmax, en))
-                    continue;
-                // the original direction is recovered exactly only for the hoisted constants, so the
-                // sphere / rect tests take it from the reciprocal-free copy kept by the caller
-                const D3 dir = d3(tv.trr.dir_x, tv.trr.dir_y, tv.trr.dir_z);
-                if (pr.kind == RT_PRIM_SPHERE) {
-                    if (!sphere_core(pr, o, dir, tmin, tmax, t)) continue;
-                } else {
-                    double a, b;
-                    D3 to, td;
-                    if (!rect_core(sc, pr, o, dir, tmin, tmax, t, a, b, to, td)) continue;
-                }
-            }
-            if (tv.best_prim < 0 || t < tv.best_t || (t == tv.best_t && pi > tv.best_prim)) {
-                tv.best_t = t;
-                tv.best_prim = pi;
-            }
-        }
-    }
-    // pop, skipping subtrees that now start beyond the best hit
-    const double lim2 = tv.best_prim >= 0 ? tv.best_t * (1.0 + 1e-9) : tmax;
+// pop the next subtree that can still contain a closer hit; marks the traversal done when none is left
+RTD void trav_pop(Trav& tv, TravStack& ts) {
+    const double lim2 = tv.best_prim >= 0 ? tv.best_t * (1.0 + 1e-9) : tv.tmax;
     while (tv.sp > 0) {
         tv.sp--;
         int32_t node;
@@ -544,10 +453,107 @@ RTD bool trav_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
         stack_get(ts, tv.sp, node, et);
         if ((double)et <= lim2) {
             tv.cur = node;
-            return true;
+            tv.leaf_i = 0;
+            return;
         }
     }
-    return false;
+    tv.done = true;
+}
+
+// One internal node: test both children (one 64-B fetch), descend into the nearer, push the farther.
+template <bool COUNT>
+RTD void node_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
+    const D3 o = tv.o, inv = tv.inv;
+    const double lim = tv.best_prim >= 0 ? tv.best_t * (1.0 + 1e-9) : tv.tmax;
+    const float4* np = reinterpret_cast<const float4*>(&sc.nodes[tv.cur]);
+    const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    if (COUNT) tc->nodes++;
+    const int32_t left = __float_as_int(n3.x), right = __float_as_int(n3.y);
+    double el = 0.0, er = 0.0;
+    const bool sl = slab((double)n0.x, (double)n0.y, (double)n0.z, (double)n0.w, (double)n1.x, (double)n1.y, o, inv,
+                         tv.tmin, lim, el);
+    const bool sr = slab((double)n1.z, (double)n1.w, (double)n2.x, (double)n2.y, (double)n2.z, (double)n2.w, o, inv,
+                         tv.tmin, lim, er);
+    const bool hl = sl && left != kNoChild, hr = sr && right != kNoChild;
+    tv.leaf_i = 0;
+    if (hl && hr) {
+        const bool swap = er < el;
+        const int32_t nearc = swap ? right : left, farc = swap ? left : right;
+        const double ef = swap ? el : er;
+        stack_push(ts, tv.sp, farc, float_lower(ef));
+        tv.sp++;
+        tv.cur = nearc;
+    } else if (hl) {
+        tv.cur = left;
+    } else if (hr) {
+        tv.cur = right;
+    } else {
+        trav_pop(tv, ts);
+    }
+}
+
+// One primitive of the current leaf (leaf code: -1 - (first*8 + count-1)); pops after the last one.
+// Ties in t go to the larger prim index (ABI tie rule).
+template <bool COUNT>
+RTD void leaf_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
+    const D3 o = tv.o, inv = tv.inv;
+    const double tmin = tv.tmin, tmax = tv.tmax;
+    const uint32_t code = (uint32_t)(-1 - tv.cur);
+    const uint32_t first = code >> 3, count = (code & 7u) + 1u;
+    const uint32_t slot = first + tv.leaf_i;
+    const uint32_t e = sc.leaf_prim[slot];
+    // the vertex slot address does not depend on `e`: its loads are issued beside the id load
+    const double* tvp = sc.leaf_tri + (size_t)slot * 9;
+    const double2 q0 = *reinterpret_cast<const double2*>(tvp);
+    const double2 q1 = *reinterpret_cast<const double2*>(tvp + 2);
+    const double2 q2 = *reinterpret_cast<const double2*>(tvp + 4);
+    const double2 q3 = *reinterpret_cast<const double2*>(tvp + 6);
+    const double q4 = tvp[8];
+    double t = 0.0;
+    int32_t pi = -1;
+    bool hit = false;
+    if (!(e & kLeafOther)) {
+        const D3 p0 = d3(q0.x, q0.y, q1.x), p1 = d3(q1.y, q2.x, q2.y), p2 = d3(q3.x, q3.y, q4);
+        if (COUNT) tc->tris++;
+        // the reference tests the leaf's own f64 box on the ORIGINAL interval (hittable.rs:625)
+        double en, b0, b1, b2;
+        hit = slab(rmin(p0.x, rmin(p1.x, p2.x)), rmin(p0.y, rmin(p1.y, p2.y)), rmin(p0.z, rmin(p1.z, p2.z)),
+                   rmax(p0.x, rmax(p1.x, p2.x)), rmax(p0.y, rmax(p1.y, p2.y)), rmax(p0.z, rmax(p1.z, p2.z)), o, inv,
+                   tmin, tmax, en) &&
+              tri_core(p0, p1, p2, o, tv.trr, tmax, t, b0, b1, b2);
+        pi = (int32_t)e;
+        if (hit && sc.mesh_has_uv) {  // rare path: uv-degenerate rejection (hittable.rs:373-378)
+            const rt_primitive& pr = sc.prims[pi];
+            const DevMesh& m = sc.meshes[pr.mesh_index];
+            if (m.uv) {
+                TriUv uv = tri_uvs(m, m.ind[pr.tri_ind], m.ind[pr.tri_ind + 1], m.ind[pr.tri_ind + 2]);
+                D3 du, dv;
+                hit = tri_dpdu(p0, p1, p2, uv, du, dv);
+            }
+        }
+    } else {
+        pi = (int32_t)(e & ~kLeafOther);
+        const rt_primitive& pr = sc.prims[pi];
+        if (COUNT) tc->others++;
+        double en;
+        if (slab(pr.bbox_min[0], pr.bbox_min[1], pr.bbox_min[2], pr.bbox_max[0], pr.bbox_max[1], pr.bbox_max[2], o, inv,
+                 tmin, tmax, en)) {
+            const D3 dir = d3(tv.trr.dir_x, tv.trr.dir_y, tv.trr.dir_z);
+            if (pr.kind == RT_PRIM_SPHERE) {
+                hit = sphere_core(pr, o, dir, tmin, tmax, t);
+            } else {
+                double a, b;
+                D3 to, td;
+                hit = rect_core(sc, pr, o, dir, tmin, tmax, t, a, b, to, td);
+            }
+        }
+    }
+    if (hit && (tv.best_prim < 0 || t < tv.best_t || (t == tv.best_t && pi > tv.best_prim))) {
+        tv.best_t = t;
+        tv.best_prim = pi;
+    }
+    tv.leaf_i++;
+    if (tv.leaf_i >= count) trav_pop(tv, ts);
 }
 
 // Closest hit of one ray, run to completion.  Returns prim index or -1; t_out = hit parameter.
@@ -560,7 +566,11 @@ RTD int32_t closest_hit(const DevScene& sc, D3 o, D3 dir, double tmin, double tm
     }
     Trav tv;
     trav_init(tv, sc, o, dir, tmin, tmax);
-    while (trav_step<COUNT>(tv, sc, ts, tc)) {
+    while (!tv.done) {
+        if (tv.cur >= 0)
+            node_step<COUNT>(tv, sc, ts, tc);
+        else
+            leaf_step<COUNT>(tv, sc, ts, tc);
     }
     t_out = tv.best_t;
     return tv.best_prim;

@@ -134,14 +134,18 @@ __global__ __launch_bounds__(256) void k_generate(PathState st, rt_camera cam, C
 }
 
 // --------------------------------------------------------------------- trace
-// Persistent waves with dynamic ray replacement: a lane whose ray is finished does not wait for
-// the slowest ray of its batch -- whenever kRefillLanes or more lanes of the wave are idle (or all
-// are), the idle lanes pull the next queue entries (one atomic per wave, __ballot/__popcll
-// prefix) and start them while the other lanes keep their traversal state.  Every wave leaves
-// the loop once the queue is exhausted and its own lanes are done.  (tune.refill_lanes must be <= 64.)
+// Persistent waves, while-while traversal, dynamic ray replacement.
+//   * A lane whose ray is finished does not wait for the slowest ray of its batch: whenever
+//     tune.refill_lanes or more lanes of the wave are idle (or all are), the idle lanes pull the next
+//     queue entries (one atomic per wave, __ballot/__popcll prefix) while the others keep their state.
+//   * Each round runs up to tune.node_rounds node-only steps (as long as any lane sits on an internal
+//     node) and then up to tune.leaf_rounds single-primitive steps: the wave never executes the
+//     primitive code for the sake of one lane while the rest are walking the tree, and vice versa.
+// Every wave leaves the loop once the queue is exhausted and its own lanes are done.
 struct TraceTune {
-    int refill_lanes;     // refill when at least this many lanes are idle
-    int steps_per_round;  // traversal steps between two refill checks
+    int refill_lanes;  // refill when at least this many lanes are idle (<= 64)
+    int node_rounds;   // max consecutive node-only steps per round
+    int leaf_rounds;   // max consecutive primitive steps per round
 };
 
 template <bool COUNT>
@@ -164,6 +168,8 @@ __global__ __launch_bounds__(256) void k_trace(DevScene sc, PathState st, const 
     ts.lds = &lds_stack[threadIdx.x];
     ts.lds_stride = 256;
     Trav tv;
+    tv.done = true;
+    tv.cur = 0;
     bool has_ray = false;
     bool exhausted = false;  // wave-uniform: the queue has no more entries
     uint32_t slot_kind = 0;
@@ -200,22 +206,29 @@ __global__ __launch_bounds__(256) void k_trace(DevScene sc, PathState st, const 
         }
         if (__ballot(has_ray) == 0ull) {
             if (exhausted) break;
-            continue;  // fewer than kRefillLanes idle is impossible here (all are idle): refill again
+            continue;  // all lanes idle: the refill above ran and either found rays or set `exhausted`
         }
 #pragma unroll 1
-        for (int k = 0; k < tune.steps_per_round; k++) {
-            if (has_ray) {
-                if (!trav_step<COUNT>(tv, sc, ts, &tc)) {
-                    const uint32_t slot = slot_kind & kSlotMask, kind = slot_kind >> 30;
-                    if (kind == kRayExt)
-                        st.hit_prim[slot] = tv.best_prim;
-                    else if (kind == kRayShadow)
-                        st.sh_prim[slot] = tv.best_prim;
-                    else
-                        st.pr_prim[slot] = tv.best_prim;
-                    has_ray = false;
-                }
-            }
+        for (int k = 0; k < tune.node_rounds; k++) {
+            const bool at_node = has_ray && !tv.done && tv.cur >= 0;
+            if (__ballot(at_node) == 0ull) break;
+            if (at_node) node_step<COUNT>(tv, sc, ts, &tc);
+        }
+#pragma unroll 1
+        for (int k = 0; k < tune.leaf_rounds; k++) {
+            const bool at_leaf = has_ray && !tv.done && tv.cur < 0;
+            if (__ballot(at_leaf) == 0ull) break;
+            if (at_leaf) leaf_step<COUNT>(tv, sc, ts, &tc);
+        }
+        if (has_ray && tv.done) {
+            const uint32_t slot = slot_kind & kSlotMask, kind = slot_kind >> 30;
+            if (kind == kRayExt)
+                st.hit_prim[slot] = tv.best_prim;
+            else if (kind == kRayShadow)
+                st.sh_prim[slot] = tv.best_prim;
+            else
+                st.pr_prim[slot] = tv.best_prim;
+            has_ray = false;
         }
     }
     if (COUNT) {
