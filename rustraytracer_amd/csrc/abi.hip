@@ -73,7 +73,7 @@ struct rt_context {
     uint32_t* pix_list = nullptr;
     size_t pix_capacity = 0;
     std::vector<hipEvent_t> events;
-    TraceTune tune{32, 8, 4};
+    TraceTune tune{32, 8, 4, 128};
 };
 
 struct rt_scene {
@@ -173,6 +173,7 @@ int rt_context_create(const int* device_ids, int n_devices, rt_context** out) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     if (const char* e = getenv("RT_TRACE_REFILL")) c->tune.refill_lanes = std::min(64, std::max(1, atoi(e)));
     if (const char* e = getenv("RT_TRACE_NODE_ROUNDS")) c->tune.node_rounds = std::max(1, atoi(e));
+    if (const char* e = getenv("RT_TRACE_RESERVE")) c->tune.reserve = std::max(64, atoi(e) & ~63);
     if (const char* e = getenv("RT_TRACE_LEAF_ROUNDS")) c->tune.leaf_rounds = std::max(1, atoi(e));
     if (const char* e = getenv("RT_LANES")) c->n_lanes = std::min(kLanes, std::max(1, atoi(e)));
     for (int i = 0; i < kLanes; i++) {
@@ -183,7 +184,7 @@ int rt_context_create(const int* device_ids, int n_devices, rt_context** out) {
         HIP_TRY(hipHostGetDevicePointer((void**)&ln.mirror_d, ln.mirror_h, 0));
         HIP_TRY(hipMalloc((void**)&ln.ctl, sizeof(Ctl)));
     }
-    HIP_TRY(hipMalloc((void**)&c->stats, sizeof(DevStats)));
+    HIP_TRY(hipMalloc((void**)&c->stats, sizeof(DevStats) * kStatShards));
     *out = c;
     return RT_OK;
 }
@@ -581,7 +582,7 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemsetAsync(d_rgb, 0, sizeof(double) * 3 * (size_t)W * H, stream));
     HIP_TRY(hipMemsetAsync(d_n, 0, sizeof(uint32_t) * (size_t)W * H, stream));
-    HIP_TRY(hipMemsetAsync(c->stats, 0, sizeof(DevStats), stream));
+    HIP_TRY(hipMemsetAsync(c->stats, 0, sizeof(DevStats) * kStatShards, stream));
     const size_t NP = pix.size();
     double kernel_ms = 0.0, trace_ms = 0.0;
     uint64_t trace_launches = 0;
@@ -698,8 +699,14 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
         HIP_TRY(hipStreamSynchronize(stream));
     }
     if (stats) {
-        DevStats ds;
-        HIP_TRY(hipMemcpy(&ds, c->stats, sizeof(ds), hipMemcpyDeviceToHost));
+        DevStats shards[kStatShards];
+        HIP_TRY(hipMemcpy(shards, c->stats, sizeof(shards), hipMemcpyDeviceToHost));
+        DevStats ds{};
+        for (int i = 0; i < kStatShards; i++) {
+            ds.paths += shards[i].paths; ds.r1 += shards[i].r1; ds.r2 += shards[i].r2; ds.r3 += shards[i].r3;
+            ds.vertices += shards[i].vertices; ds.nodes += shards[i].nodes; ds.tris += shards[i].tris;
+            ds.others += shards[i].others;
+        }
         std::memset(stats, 0, sizeof(*stats));
         stats->paths = ds.paths;
         stats->rays_extension = ds.r1;

@@ -43,7 +43,7 @@ RTD double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 RTD D3 cross(D3 a, D3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 RTD double norm2(D3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
 RTD double norm(D3 a) { return dm_sqrt(norm2(a)); }
-RTD D3 normalize(D3 a) { return a / norm(a); }
+RTDN D3 normalize(D3 a) { return a / norm(a); }
 RTD bool is_black(D3 a) { return a.x == 0.0 && a.y == 0.0 && a.z == 0.0; }
 RTD D3 black() { return {0.0, 0.0, 0.0}; }
 RTD D3 white() { return {1.0, 1.0, 1.0}; }

@@ -82,6 +82,10 @@ RTD void wave_count(bool pred, unsigned long long* counter) {
     const uint32_t lane = threadIdx.x & 63u;
     if ((int)lane == __ffsll((long long)mask) - 1) atomicAdd(counter, (unsigned long long)__popcll(mask));
 }
+// Same-address atomics saturate near 88 per microsecond on this chip, so the hot counters are
+// (a) aggregated per 256-thread block through LDS (one atomic per block) and (b) for the statistics,
+// spread over kStatShards cache lines that the host sums.
+RTD DevStats* stat_shard(DevStats* stats) { return stats + (blockIdx.x & (kStatShards - 1)); }
 
 // ------------------------------------------------------------------ generate
 // integrator.rs:357-366 + sampler.rs:606-613 + geometry.rs:177-190 (+ util.rs:105-113)
@@ -136,8 +140,10 @@ __global__ __launch_bounds__(256) void k_generate(PathState st, rt_camera cam, C
 // --------------------------------------------------------------------- trace
 // Persistent waves, while-while traversal, dynamic ray replacement.
 //   * A lane whose ray is finished does not wait for the slowest ray of its batch: whenever
-//     tune.refill_lanes or more lanes of the wave are idle (or all are), the idle lanes pull the next
-//     queue entries (one atomic per wave, __ballot/__popcll prefix) while the others keep their state.
+//     tune.refill_lanes or more lanes of the wave are idle (or all are), the idle lanes take the next
+//     queue entries (__ballot/__popcll prefix) while the others keep their state.  Entries come from a
+//     per-wave reservation of tune.reserve entries, so the single queue head sees one atomic per
+//     reservation, not per refill (same-address atomics saturate near 88/us).
 //   * Each round runs up to tune.node_rounds node-only steps (as long as any lane sits on an internal
 //     node) and then up to tune.leaf_rounds single-primitive steps: the wave never executes the
 //     primitive code for the sake of one lane while the rest are walking the tree, and vice versa.
@@ -146,6 +152,7 @@ struct TraceTune {
     int refill_lanes;  // refill when at least this many lanes are idle (<= 64)
     int node_rounds;   // max consecutive node-only steps per round
     int leaf_rounds;   // max consecutive primitive steps per round
+    int reserve;       // queue entries a wave reserves per atomic (refills are served from the reservation)
 };
 
 template <bool COUNT>
@@ -171,19 +178,35 @@ __global__ __launch_bounds__(256) void k_trace(DevScene sc, PathState st, const 
     tv.done = true;
     tv.cur = 0;
     bool has_ray = false;
-    bool exhausted = false;  // wave-uniform: the queue has no more entries
+    bool exhausted = false;  // wave-uniform: the queue and this wave's reservation have no more entries
     uint32_t slot_kind = 0;
+    uint32_t res_next = 0, res_end = 0;  // wave-uniform: [res_next, res_end) is reserved for this wave
+    // small queues: shrink the reservation so that the tail still spreads over the waves
+    const uint32_t n_waves = gridDim.x * 4u;
+    uint32_t reserve = (uint32_t)tune.reserve;
+    while (reserve > 64u && (uint64_t)reserve * n_waves * 4u > n) reserve >>= 1;
     for (;;) {
         const unsigned long long idle = __ballot(!has_ray);
         const int n_idle = __popcll(idle);
         if (!exhausted && (n_idle >= tune.refill_lanes)) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&ctl->head[it], (uint32_t)n_idle);
-            base = __shfl(base, 0, 64);
-            if (base + (uint32_t)n_idle >= n) exhausted = true;
-            if (!has_ray) {
-                const uint32_t idx = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                if (idx < n) {
+            if (res_next >= res_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&ctl->head[it], reserve);
+                base = __shfl(base, 0, 64);
+                res_next = base;
+                res_end = base + reserve < n ? base + reserve : n;
+                if (base >= n) {
+                    res_end = res_next;
+                    exhausted = true;
+                }
+            }
+            if (!exhausted) {
+                const uint32_t base = res_next;
+                const uint32_t take = (uint32_t)n_idle < res_end - res_next ? (uint32_t)n_idle : res_end - res_next;
+                res_next += take;
+                const uint32_t my = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                const uint32_t idx = base + my;
+                if (!has_ray && my < take) {
                     const uint32_t e = queue[idx];
                     const uint32_t slot = e & kSlotMask, kind = e >> 30;
                     D3 o = ld3(st.ox, st.oy, st.oz, slot);
@@ -232,9 +255,10 @@ __global__ __launch_bounds__(256) void k_trace(DevScene sc, PathState st, const 
         }
     }
     if (COUNT) {
-        atomicAdd(&stats->nodes, (unsigned long long)tc.nodes);
-        atomicAdd(&stats->tris, (unsigned long long)tc.tris);
-        atomicAdd(&stats->others, (unsigned long long)tc.others);
+        DevStats* sh = stat_shard(stats);
+        atomicAdd(&sh->nodes, (unsigned long long)tc.nodes);
+        atomicAdd(&sh->tris, (unsigned long long)tc.tris);
+        atomicAdd(&sh->others, (unsigned long long)tc.others);
     }
 }
 
@@ -260,13 +284,16 @@ __global__ __launch_bounds__(256) void k_intersect_batch(DevScene sc, const rt_r
 }
 
 // --------------------------------------------------------------------- shade
-__global__ __launch_bounds__(256) void k_shade(DevScene sc, PathState in, PathState out, Ctl* ctl, int it,
+__global__ __launch_bounds__(256, 3) void k_shade(DevScene sc, PathState in, PathState out, Ctl* ctl, int it,
                                                uint32_t max_depth, uint32_t* queue_out, double* lfx, double* lfy,
                                                double* lfz, DevStats* stats) {
     const uint32_t n_active = ctl->n_active[it];
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    // whole wave past the end: nothing to do (wave-uniform exit keeps ballots well-formed)
-    if ((slot & ~63u) >= n_active) return;
+    // whole block past the end: nothing to do (block-uniform exit: the block barriers below stay well-formed)
+    if (blockIdx.x * blockDim.x >= n_active) return;
+    __shared__ uint32_t s_cnt[4][4];  // [wave][0 = output slots, 1..3 = ext / shadow / probe rays]
+    __shared__ uint32_t s_base[2];    // block's base in the next path list / ray queue
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const bool valid = slot < n_active;
     const uint32_t fl = valid ? in.flags[slot] : kDead;
     const bool live = valid && !(fl & kDead);
@@ -325,7 +352,20 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, PathState in, PathSt
     // a vertex that will be shaded gets its output slot now (dense, wave-contiguous); if the path
     // then ends without pending light terms the slot is marked dead and skipped next bounce
     const bool will_shade = active && is_some && bounces < max_depth;
-    const uint32_t os = wave_alloc(will_shade, &ctl->n_active[it + 1]);
+    uint32_t os;
+    {   // one atomic per block: wave counts -> LDS -> block base -> per-lane slot
+        const unsigned long long m = __ballot(will_shade);
+        if (lane == 0) s_cnt[wave][0] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t tot = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0];
+            s_base[0] = tot ? atomicAdd(&ctl->n_active[it + 1], tot) : 0u;
+        }
+        __syncthreads();
+        uint32_t off = s_base[0];
+        for (uint32_t w = 0; w < wave; w++) off += s_cnt[w][0];
+        os = off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    }
     if (will_shade) {
         uint64_t rng = in.rng[slot];
         Bsdf bsdf;
@@ -443,14 +483,41 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, PathState in, PathSt
         lfy[og] = L.y;
         lfz[og] = L.z;
     }
-    // ---- rays of the next bounce, appended wave by wave: [extension][shadow][probe]
-    wave_append(emit_ext, os | (kRayExt << 30), queue_out, &ctl->n_rays[it + 1]);
-    wave_append(emit_sh, os | (kRayShadow << 30), queue_out, &ctl->n_rays[it + 1]);
-    wave_append(emit_pr, os | (kRayProbe << 30), queue_out, &ctl->n_rays[it + 1]);
-    wave_count(emit_ext, &stats->r1);
-    wave_count(emit_sh, &stats->r2);
-    wave_count(emit_pr, &stats->r3);
-    wave_count(shaded, &stats->vertices);
+    // ---- rays of the next bounce: one queue reservation per block, laid out wave by wave as
+    // [extension][shadow][probe]; statistics: one atomic per block and counter, on this block's shard
+    {
+        const unsigned long long me = __ballot(emit_ext), ms = __ballot(emit_sh), mp = __ballot(emit_pr);
+        const uint32_t ce = (uint32_t)__popcll(me), cs = (uint32_t)__popcll(ms), cp = (uint32_t)__popcll(mp);
+        if (lane == 0) {
+            s_cnt[wave][1] = ce;
+            s_cnt[wave][2] = cs;
+            s_cnt[wave][3] = cp;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t te = 0, tsd = 0, tp = 0, tv = 0;
+            for (int w = 0; w < 4; w++) {
+                te += s_cnt[w][1];
+                tsd += s_cnt[w][2];
+                tp += s_cnt[w][3];
+                tv += s_cnt[w][0];
+            }
+            const uint32_t tot = te + tsd + tp;
+            s_base[1] = tot ? atomicAdd(&ctl->n_rays[it + 1], tot) : 0u;
+            DevStats* sh = stat_shard(stats);
+            if (te) atomicAdd(&sh->r1, (unsigned long long)te);
+            if (tsd) atomicAdd(&sh->r2, (unsigned long long)tsd);
+            if (tp) atomicAdd(&sh->r3, (unsigned long long)tp);
+            if (tv) atomicAdd(&sh->vertices, (unsigned long long)tv);
+        }
+        __syncthreads();
+        uint32_t off = s_base[1];
+        for (uint32_t w = 0; w < wave; w++) off += s_cnt[w][1] + s_cnt[w][2] + s_cnt[w][3];
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (emit_ext) queue_out[off + (uint32_t)__popcll(me & below)] = os | (kRayExt << 30);
+        if (emit_sh) queue_out[off + ce + (uint32_t)__popcll(ms & below)] = os | (kRayShadow << 30);
+        if (emit_pr) queue_out[off + ce + cs + (uint32_t)__popcll(mp & below)] = os | (kRayProbe << 30);
+    }
 }
 
 // ------------------------------------------------------------------- resolve

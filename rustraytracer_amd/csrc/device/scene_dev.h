@@ -77,8 +77,10 @@ constexpr uint32_t kLightShift = 16;
 constexpr uint32_t kRayExt = 0u, kRayShadow = 1u, kRayProbe = 2u;
 constexpr uint32_t kSlotMask = 0x3fffffffu;
 
-struct DevStats {
+struct DevStats {  // one shard = two 64-B lines; kStatShards shards, summed by the host
     unsigned long long paths, r1, r2, r3, vertices, nodes, tris, others;
+    unsigned long long pad[8];
 };
+constexpr int kStatShards = 64;
 
 }  // namespace rtd

@@ -48,7 +48,10 @@ RTD D3 rand_cosine_dir(double r1, double r2) {
 }
 
 // material.rs:542-565: Checkered follows even/odd ids (bounded depth, like the oracle)
-RTD D3 texture_value(const DevScene& sc, uint32_t index, double u, double v) {
+// noinline + rolled loop: inlining this (two dm_sin per checker level, eight levels, a dozen call
+// sites in compute_scattering) multiplied k_shade's code size several times over the I-cache.
+RTDN D3 texture_value(const DevScene& sc, uint32_t index, double u, double v) {
+#pragma unroll 1
     for (int depth = 0; depth < 8; depth++) {
         const rt_texture& t = sc.texs[index];
         if (t.kind != RT_TEX_CHECKERED) break;
