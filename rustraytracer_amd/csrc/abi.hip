@@ -47,12 +47,11 @@ struct Lane {
     uint32_t capacity = 0;
     void* pool = nullptr;
     PathState st[2] = {};
-    double* lf[3] = {nullptr, nullptr, nullptr};  // film staging: radiance of retired paths
     uint32_t* queue[2] = {nullptr, nullptr};
     Ctl* ctl = nullptr;
     MirrorEntry* mirror_h = nullptr;  // pinned + mapped: counters published by k_trace
     MirrorEntry* mirror_d = nullptr;
-    uint32_t chunk_seq = 0;
+    uint32_t seq = 1;  // next mirror sequence number (unique per iteration ever launched on this lane)
     std::vector<hipEvent_t> events;
     size_t ev_i = 0;
     // per-render results of this lane
@@ -68,8 +67,11 @@ struct rt_context {
     int num_cus = 256;
     hipStream_t stream = nullptr;
     Lane lanes[kLanes];
-    int n_lanes = kLanes;
+    int n_lanes = 1;  // RT_LANES=2 runs two pools concurrently (same throughput once the pool is large)
     DevStats* stats = nullptr;
+    BatchCtl* batch = nullptr;
+    double* lf[3] = {nullptr, nullptr, nullptr};  // film staging of the current batch: radiance of retired paths
+    size_t lf_capacity = 0;
     uint32_t* pix_list = nullptr;
     size_t pix_capacity = 0;
     std::vector<hipEvent_t> events;
@@ -104,9 +106,9 @@ static int ensure_lane_capacity(rt_context* c, Lane& ln, uint32_t cap) {
         ln.pool = nullptr;
         ln.capacity = 0;
     }
-    // one slab: 2 x (27 double arrays, rng, 3 result arrays, flags, orig), film staging, 2 ray queues
+    // one slab: 2 x (27 double arrays, rng, 3 result arrays, flags, orig), 2 ray queues
     const size_t n = cap;
-    const size_t bytes = n * (2 * (27 * 8 + 8 + 3 * 4 + 4 + 4) + 3 * 8 + 2 * 3 * 4) + 4096;
+    const size_t bytes = n * (2 * (27 * 8 + 8 + 3 * 4 + 4 + 4) + 2 * 3 * 4) + 4096;
     HIP_TRY(hipMalloc(&ln.pool, bytes));
     char* p = (char*)ln.pool;
     for (int b = 0; b < 2; b++) {
@@ -124,10 +126,6 @@ static int ensure_lane_capacity(rt_context* c, Lane& ln, uint32_t cap) {
         st.pr_prim = (int32_t*)p; p += n * 4;
         st.flags = (uint32_t*)p; p += n * 4;
         st.orig = (uint32_t*)p; p += n * 4;
-    }
-    for (int a = 0; a < 3; a++) {
-        ln.lf[a] = (double*)p;
-        p += n * 8;
     }
     ln.queue[0] = (uint32_t*)p; p += n * 12;
     ln.queue[1] = (uint32_t*)p; p += n * 12;
@@ -179,12 +177,13 @@ int rt_context_create(const int* device_ids, int n_devices, rt_context** out) {
     for (int i = 0; i < kLanes; i++) {
         Lane& ln = c->lanes[i];
         HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
-        HIP_TRY(hipHostMalloc((void**)&ln.mirror_h, sizeof(MirrorEntry) * 264, hipHostMallocMapped | hipHostMallocCoherent));
-        std::memset(ln.mirror_h, 0, sizeof(MirrorEntry) * 264);
+        HIP_TRY(hipHostMalloc((void**)&ln.mirror_h, sizeof(MirrorEntry) * kRing, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(ln.mirror_h, 0, sizeof(MirrorEntry) * kRing);
         HIP_TRY(hipHostGetDevicePointer((void**)&ln.mirror_d, ln.mirror_h, 0));
         HIP_TRY(hipMalloc((void**)&ln.ctl, sizeof(Ctl)));
     }
     HIP_TRY(hipMalloc((void**)&c->stats, sizeof(DevStats) * kStatShards));
+    HIP_TRY(hipMalloc((void**)&c->batch, sizeof(BatchCtl)));
     *out = c;
     return RT_OK;
 }
@@ -202,6 +201,8 @@ int rt_context_destroy(rt_context* c) {
         if (ln.stream) (void)hipStreamDestroy(ln.stream);
     }
     if (c->stats) (void)hipFree(c->stats);
+    if (c->batch) (void)hipFree(c->batch);
+    if (c->lf[0]) (void)hipFree(c->lf[0]);
     if (c->pix_list) (void)hipFree(c->pix_list);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -438,11 +439,9 @@ struct RenderJob {
     rt_scene* s;
     rt_camera cam;
     const rt_render_cfg* cfg;
-    double* d_rgb;
-    uint32_t* d_n;
-    std::vector<ChunkDesc> chunks;
-    std::vector<hipEvent_t> resolved;  // recorded after chunk i's k_resolve
-    std::atomic<int> n_resolved{0};    // chunks whose resolve event has been recorded (host side, in order)
+    ChunkDesc batch;                 // the batch both lanes are working on
+    unsigned long long batch_total;  // its camera samples
+    uint32_t pool;                   // paths each lane keeps in flight
     std::atomic<bool> abort{false};
     int trace_blocks;
     bool count_trav;
@@ -465,95 +464,97 @@ static int lane_fail(Lane& ln, int code, const char* fmt, ...) {
         }                                                                                                   \
     } while (0)
 
-// Enqueue every chunk with index == lane_id (mod n_lanes) on this lane's stream.
-static int run_lane(RenderJob& job, int lane_id, int n_lanes) {
+// One lane's share of a batch: keep `pool` paths alive, topping up from the shared batch counter,
+// until the batch is exhausted and this lane's paths have all retired.
+static int run_lane(RenderJob& job, int lane_id) {
     rt_context* c = job.c;
     Lane& ln = c->lanes[lane_id];
     const rt_render_cfg* cfg = job.cfg;
     LANE_TRY(hipSetDevice(c->device));
-    const uint32_t iters = cfg->max_depth + 1;
     static const bool no_ev = getenv("RT_NO_TRACE_EVENTS") != nullptr;
-    for (size_t ci = (size_t)lane_id; ci < job.chunks.size(); ci += (size_t)n_lanes) {
+    hipStream_t stream = ln.stream;
+    const uint32_t P = job.pool;
+    const uint32_t gen_blocks = (P + 255) / 256;
+    LANE_TRY(hipMemsetAsync(ln.ctl, 0, sizeof(Ctl), stream));
+    const uint32_t seq0 = ln.seq;
+    // enough for every sample to be started and for the deepest path to finish, with slack
+    const unsigned long long max_iters =
+        (job.batch_total / std::max<uint32_t>(P, 1u) + 2ull) * ((unsigned long long)cfg->max_depth + 3ull) + 64ull;
+    uint32_t bound_active = P;
+    bool exhausted_known = false;
+    unsigned long long it = 0;
+    for (; it < max_iters; it++) {
         if (job.abort.load()) return RT_ERR_HIP;
-        const ChunkDesc& ck = job.chunks[ci];
-        const uint32_t total = ck.n_pixels * ck.n_samples;
-        const uint32_t blocks = (total + 255) / 256;
-        hipStream_t stream = ln.stream;
-        LANE_TRY(hipMemsetAsync(ln.ctl, 0, sizeof(Ctl), stream));
-        hipLaunchKernelGGL(k_generate, dim3(blocks), dim3(256), 0, stream, ln.st[0], job.cam, ck, c->pix_list,
-                           ln.queue[0], ln.ctl, c->stats);
-        const uint32_t seq = ++ln.chunk_seq;
-        uint32_t bound_active = total;  // upper bound of n_active for the iteration being launched
-        for (uint32_t it = 0; it < iters; it++) {
-            if (it >= 2) {
-                // counters published when k_trace(it-2) started; two iterations stay queued behind it
-                volatile MirrorEntry* me = &ln.mirror_h[it - 2];
-                const auto t0 = std::chrono::steady_clock::now();
-                uint64_t spins = 0;
-                while (__atomic_load_n(&me->seq, __ATOMIC_ACQUIRE) != seq) {
-                    if ((++spins & 0xfff) == 0) {
-                        if (job.abort.load()) return RT_ERR_HIP;
-                        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
-                            job.abort.store(true);
-                            return lane_fail(ln, RT_ERR_HIP, "device did not publish iteration %u counters within 30 s", it - 2);
-                        }
-                    }
-                }
-                bound_active = std::min(bound_active, (uint32_t)me->n_active);
-                if (bound_active == 0) break;  // every path has retired
-            }
-            const uint32_t shade_blocks = (bound_active + 255) / 256;
-            const uint32_t need_blocks =
-                (uint32_t)std::min<uint64_t>((3ull * bound_active + 255) / 256, (uint64_t)job.trace_blocks);
-            const uint32_t tblocks = std::max(1u, need_blocks);
-            hipEvent_t a = nullptr, b = nullptr;
-            if (!no_ev) {
-                a = get_event(ln.events, ln.ev_i++);
-                b = get_event(ln.events, ln.ev_i++);
-                if (!a || !b) {
-                    job.abort.store(true);
-                    return lane_fail(ln, RT_ERR_HIP, "hipEventCreate failed");
-                }
-                LANE_TRY(hipEventRecord(a, stream));
-            }
-            if (job.count_trav)
-                hipLaunchKernelGGL(k_trace<true>, dim3(tblocks), dim3(256), 0, stream, job.s->dev, ln.st[it & 1],
-                                   ln.queue[it & 1], ln.ctl, (int)it, c->stats, c->tune, ln.mirror_d, seq);
-            else
-                hipLaunchKernelGGL(k_trace<false>, dim3(tblocks), dim3(256), 0, stream, job.s->dev, ln.st[it & 1],
-                                   ln.queue[it & 1], ln.ctl, (int)it, c->stats, c->tune, ln.mirror_d, seq);
-            if (!no_ev) {
-                LANE_TRY(hipEventRecord(b, stream));
-                ln.trace_ev.emplace_back(a, b);
-            }
-            ln.trace_launches++;
-            hipLaunchKernelGGL(k_shade, dim3(shade_blocks), dim3(256), 0, stream, job.s->dev, ln.st[it & 1],
-                               ln.st[(it + 1) & 1], ln.ctl, (int)it, cfg->max_depth, ln.queue[(it + 1) & 1], ln.lf[0],
-                               ln.lf[1], ln.lf[2], c->stats);
-        }
-        // film: chunks add their samples in chunk order (sample order per pixel), whatever lane ran them
-        if (ci > 0) {
+        if (it >= 2) {
+            // counters published when k_trace(it-2) started; two iterations stay queued behind it
+            volatile MirrorEntry* me = &ln.mirror_h[(it - 2) % kRing];
+            const uint32_t want_seq = seq0 + (uint32_t)(it - 2);
             const auto t0 = std::chrono::steady_clock::now();
             uint64_t spins = 0;
-            while (job.n_resolved.load(std::memory_order_acquire) < (int)ci) {
+            while (__atomic_load_n(&me->seq, __ATOMIC_ACQUIRE) != want_seq) {
                 if ((++spins & 0xfff) == 0) {
                     if (job.abort.load()) return RT_ERR_HIP;
-                    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
+                    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
                         job.abort.store(true);
-                        return lane_fail(ln, RT_ERR_HIP, "chunk %zu never resolved", ci - 1);
+                        return lane_fail(ln, RT_ERR_HIP, "device did not publish iteration %llu counters within 30 s", it - 2);
                     }
                 }
             }
-            LANE_TRY(hipStreamWaitEvent(stream, job.resolved[ci - 1], 0));
+            const uint32_t live = me->n_active, rem = me->remaining;
+            if (rem == 0) {
+                // the batch has been handed out completely: from here on the lane only drains
+                exhausted_known = true;
+                bound_active = std::min(bound_active, live);
+                if (live == 0) break;
+            }
         }
-        hipLaunchKernelGGL(k_resolve, dim3((ck.n_pixels + 255) / 256), dim3(256), 0, stream, ln.lf[0], ln.lf[1],
-                           ln.lf[2], ck, c->pix_list, job.d_rgb, job.d_n);
-        LANE_TRY(hipGetLastError());
-        LANE_TRY(hipEventRecord(job.resolved[ci], stream));
-        job.n_resolved.store((int)ci + 1, std::memory_order_release);
+        // top up the pool with new camera samples, then trace and shade everything alive
+        hipLaunchKernelGGL(k_plan, dim3(1), dim3(1), 0, stream, ln.ctl, c->batch, (uint32_t)it, P, job.batch_total, c->stats);
+        if (!exhausted_known)
+            hipLaunchKernelGGL(k_generate, dim3(gen_blocks), dim3(256), 0, stream, ln.st[it & 1], job.cam, job.batch,
+                               c->pix_list, ln.queue[it & 1], ln.ctl);
+        const uint32_t shade_blocks = std::max(1u, (bound_active + 255) / 256);
+        const uint32_t tblocks = std::max(
+            1u, (uint32_t)std::min<uint64_t>((3ull * bound_active + 255) / 256, (uint64_t)job.trace_blocks));
+        hipEvent_t a = nullptr, b = nullptr;
+        if (!no_ev) {
+            a = get_event(ln.events, ln.ev_i++);
+            b = get_event(ln.events, ln.ev_i++);
+            if (!a || !b) {
+                job.abort.store(true);
+                return lane_fail(ln, RT_ERR_HIP, "hipEventCreate failed");
+            }
+            LANE_TRY(hipEventRecord(a, stream));
+        }
+        const uint32_t seq = seq0 + (uint32_t)it;
+        if (job.count_trav)
+            hipLaunchKernelGGL(k_trace<true>, dim3(tblocks), dim3(256), 0, stream, job.s->dev, ln.st[it & 1],
+                               ln.queue[it & 1], ln.ctl, (uint32_t)it, c->stats, c->tune, ln.mirror_d, seq, c->batch,
+                               job.batch_total);
+        else
+            hipLaunchKernelGGL(k_trace<false>, dim3(tblocks), dim3(256), 0, stream, job.s->dev, ln.st[it & 1],
+                               ln.queue[it & 1], ln.ctl, (uint32_t)it, c->stats, c->tune, ln.mirror_d, seq, c->batch,
+                               job.batch_total);
+        if (!no_ev) {
+            LANE_TRY(hipEventRecord(b, stream));
+            ln.trace_ev.emplace_back(a, b);
+        }
+        ln.trace_launches++;
+        hipLaunchKernelGGL(k_shade, dim3(shade_blocks), dim3(256), 0, stream, job.s->dev, ln.st[it & 1],
+                           ln.st[(it + 1) & 1], ln.ctl, (uint32_t)it, cfg->max_depth, ln.queue[(it + 1) & 1], c->lf[0],
+                           c->lf[1], c->lf[2], c->stats);
     }
+    ln.seq = seq0 + (uint32_t)it + 8u;
+    if (it >= max_iters) {
+        job.abort.store(true);
+        return lane_fail(ln, RT_ERR_HIP, "lane %d did not drain within %llu iterations", lane_id, max_iters);
+    }
+    LANE_TRY(hipGetLastError());
+    LANE_TRY(hipStreamSynchronize(stream));
     return RT_OK;
 }
+
+constexpr size_t kBatchMax = (size_t)1 << 26;  // camera samples per batch (film staging: 24 B each)
 
 static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const rt_render_cfg* cfg, double* d_rgb,
                        uint32_t* d_n, hipStream_t stream, rt_stats* stats) {
@@ -587,48 +588,38 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
     double kernel_ms = 0.0, trace_ms = 0.0;
     uint64_t trace_launches = 0;
     if (NP > 0) {
-        uint32_t P = cfg->paths_in_flight ? cfg->paths_in_flight : (1u << 22);
-        P = std::max<uint32_t>(64u, std::min<uint32_t>(P, 1u << 26));
-        P &= ~63u;
-        // chunk shape: PB pixels x spc samples
-        uint32_t PB, spc;
-        if (NP * (size_t)spp <= P) {
+        // batch shape: PB pixels x ns samples, at most kBatchMax camera samples (film staging size)
+        uint32_t PB, ns;
+        if (NP * (size_t)spp <= kBatchMax) {
             PB = (uint32_t)NP;
-            spc = spp;
-        } else if (NP <= P) {
+            ns = spp;
+        } else if (NP <= kBatchMax) {
             PB = (uint32_t)NP;
-            spc = 1;
-            while ((size_t)PB * spc * 2 <= P && spc * 2 <= spp) spc *= 2;
+            ns = 1;
+            while ((size_t)PB * ns * 2 <= kBatchMax && ns * 2 <= spp) ns *= 2;
         } else {
-            PB = P;
-            spc = 1;
+            PB = (uint32_t)kBatchMax;
+            ns = 1;
         }
-        RenderJob job;
-        job.c = c;
-        job.s = s;
-        job.cam = *cam;
-        job.cfg = cfg;
-        job.d_rgb = d_rgb;
-        job.d_n = d_n;
-        for (size_t pb = 0; pb < NP; pb += PB) {
-            const uint32_t npx = (uint32_t)std::min<size_t>(PB, NP - pb);
-            for (uint32_t sb = 0; sb < spp; sb += spc) {
-                ChunkDesc ck;
-                ck.n_pixels = npx;
-                ck.n_samples = spc;
-                ck.pixel_base = (uint32_t)pb;
-                ck.sample_base = sb;
-                ck.width = W;
-                ck.height = H;
-                ck.seed = cfg->seed;
-                job.chunks.push_back(ck);
-            }
-        }
-        const int n_lanes = (int)std::min<size_t>((size_t)c->n_lanes, job.chunks.size());
-        const uint32_t cap = (uint32_t)((((size_t)PB * spc) + 63) & ~(size_t)63);
+        const size_t batch_cap = (size_t)PB * ns;
+        // pool per lane
+        uint32_t P = cfg->paths_in_flight ? cfg->paths_in_flight : (1u << 24);
+        P = std::max<uint32_t>(64u, std::min<uint32_t>(P, 1u << 26));
+        P = (P + 63u) & ~63u;
+        const int n_lanes = (batch_cap > (size_t)P) ? c->n_lanes : 1;
+        P = (uint32_t)std::min<size_t>(P, (batch_cap + 63) & ~(size_t)63);
         for (int i = 0; i < n_lanes; i++) {
-            int rc = ensure_lane_capacity(c, c->lanes[i], cap);
+            int rc = ensure_lane_capacity(c, c->lanes[i], P);
             if (rc != RT_OK) return rc;
+        }
+        if (c->lf_capacity < batch_cap) {
+            if (c->lf[0]) HIP_TRY(hipFree(c->lf[0]));
+            c->lf[0] = c->lf[1] = c->lf[2] = nullptr;
+            c->lf_capacity = 0;
+            HIP_TRY(hipMalloc((void**)&c->lf[0], batch_cap * 3 * sizeof(double)));
+            c->lf[1] = c->lf[0] + batch_cap;
+            c->lf[2] = c->lf[1] + batch_cap;
+            c->lf_capacity = batch_cap;
         }
         if (c->pix_capacity < NP) {
             if (c->pix_list) HIP_TRY(hipFree(c->pix_list));
@@ -637,6 +628,12 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
             c->pix_capacity = NP;
         }
         HIP_TRY(hipMemcpyAsync(c->pix_list, pix.data(), NP * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        RenderJob job;
+        job.c = c;
+        job.s = s;
+        job.cam = *cam;
+        job.cfg = cfg;
+        job.pool = P;
         job.count_trav = (cfg->flags & RT_RENDER_COUNT_TRAVERSAL) != 0;
         // persistent grid = what is resident at once (more blocks would only queue behind them)
         int occ_t = 0, occ_c = 0;
@@ -647,40 +644,53 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
         job.trace_blocks = c->num_cus * per_cu;
         size_t ev_i = 0;
         hipEvent_t ev_begin = get_event(c->events, ev_i++), ev_end = get_event(c->events, ev_i++);
-        if (!ev_begin || !ev_end) return fail(RT_ERR_HIP, "hipEventCreate failed");
-        for (size_t i = 0; i < job.chunks.size(); i++) {
-            hipEvent_t e = get_event(c->events, ev_i++);
-            if (!e) return fail(RT_ERR_HIP, "hipEventCreate failed");
-            job.resolved.push_back(e);
-        }
+        hipEvent_t ev_ready = get_event(c->events, ev_i++);
+        if (!ev_begin || !ev_end || !ev_ready) return fail(RT_ERR_HIP, "hipEventCreate failed");
         HIP_TRY(hipEventRecord(ev_begin, stream));
         for (int i = 0; i < n_lanes; i++) {
             Lane& ln = c->lanes[i];
             ln.ev_i = 0;
             ln.trace_ev.clear();
             ln.trace_launches = 0;
-            ln.rc = RT_OK;
-            ln.err[0] = 0;
-            HIP_TRY(hipStreamWaitEvent(ln.stream, ev_begin, 0));  // film / stats zeroing and pix_list upload first
         }
-        std::vector<std::thread> workers;
-        for (int i = 1; i < n_lanes; i++) workers.emplace_back([&job, i, n_lanes] { run_lane(job, i, n_lanes); });
-        run_lane(job, 0, n_lanes);
-        for (auto& t : workers) t.join();
-        for (int i = 0; i < n_lanes; i++) {
-            Lane& ln = c->lanes[i];
-            if (ln.rc != RT_OK) {
-                (void)hipDeviceSynchronize();
-                return fail(ln.rc, "%s", ln.err);
+        for (size_t pb = 0; pb < NP; pb += PB) {
+            const uint32_t npx = (uint32_t)std::min<size_t>(PB, NP - pb);
+            for (uint32_t sb = 0; sb < spp; sb += ns) {
+                ChunkDesc& ck = job.batch;
+                ck.n_pixels = npx;
+                ck.n_samples = ns;
+                ck.pixel_base = (uint32_t)pb;
+                ck.sample_base = sb;
+                ck.width = W;
+                ck.height = H;
+                ck.seed = cfg->seed;
+                job.batch_total = (unsigned long long)npx * ns;
+                // the lanes start after everything queued on the caller's stream so far (film zeroing,
+                // pixel list upload, the previous batch's resolve)
+                HIP_TRY(hipMemsetAsync(c->batch, 0, sizeof(BatchCtl), stream));
+                HIP_TRY(hipEventRecord(ev_ready, stream));
+                for (int i = 0; i < n_lanes; i++) {
+                    Lane& ln = c->lanes[i];
+                    ln.rc = RT_OK;
+                    ln.err[0] = 0;
+                    HIP_TRY(hipStreamWaitEvent(ln.stream, ev_ready, 0));
+                }
+                std::vector<std::thread> workers;
+                for (int i = 1; i < n_lanes; i++) workers.emplace_back([&job, i] { run_lane(job, i); });
+                run_lane(job, 0);
+                for (auto& t : workers) t.join();
+                for (int i = 0; i < n_lanes; i++) {
+                    Lane& ln = c->lanes[i];
+                    if (ln.rc != RT_OK) {
+                        (void)hipDeviceSynchronize();
+                        return fail(ln.rc, "%s", ln.err);
+                    }
+                }
+                // every lane has drained (run_lane synchronises its stream): add the batch to the film
+                hipLaunchKernelGGL(k_resolve, dim3((npx + 255) / 256), dim3(256), 0, stream, c->lf[0], c->lf[1], c->lf[2],
+                                   ck, c->pix_list, d_rgb, d_n);
+                HIP_TRY(hipGetLastError());
             }
-        }
-        // the caller's stream continues after the last chunk's film update (which follows all the others)
-        HIP_TRY(hipStreamWaitEvent(stream, job.resolved.back(), 0));
-        for (int i = 0; i < n_lanes; i++) {
-            hipEvent_t e = get_event(c->events, ev_i++);
-            if (!e) return fail(RT_ERR_HIP, "hipEventCreate failed");
-            HIP_TRY(hipEventRecord(e, c->lanes[i].stream));
-            HIP_TRY(hipStreamWaitEvent(stream, e, 0));
         }
         HIP_TRY(hipEventRecord(ev_end, stream));
         HIP_TRY(hipStreamSynchronize(stream));

@@ -1,6 +1,9 @@
 // kernels.hip -- the wavefront path-tracing kernels for gfx950 (wave64).
 //
-// One chunk = up to `paths_in_flight` camera samples.  Per bounce iteration:
+// A "batch" = up to kBatchMax camera samples of one block of pixels (the whole render when it
+// fits).  Each of the two lanes keeps up to `paths_in_flight` paths alive and runs, per iteration:
+//   k_plan + k_generate  top the lane's pool up with the batch's next camera samples (streaming
+//            regeneration: every launch stays full until the batch's single final drain)
 //   k_trace  persistent waves pull 64-ray batches from the ray queue (one atomic per
 //            wave) and run the closest-hit traversal for the three root call sites
 //            of SURVEY.md 3.2: R1 extension (integrator.rs:388), R2 shadow
@@ -25,22 +28,31 @@
 
 namespace rtd {
 
+constexpr uint32_t kRing = 512;  // per-iteration counters live in a ring indexed by it % kRing
+
 struct Ctl {
-    uint32_t n_active[264];
-    uint32_t n_rays[264];
-    uint32_t head[264];
+    uint32_t n_active[kRing];
+    uint32_t n_rays[kRing];
+    uint32_t head[kRing];
+    // written by k_plan for the k_generate that follows it
+    uint32_t gen_count, gen_first, gen_slot, gen_q;
+};
+
+// The batch being rendered, shared by both lanes.
+struct BatchCtl {
+    unsigned long long next;  // next camera sample (path index inside the batch) to generate
 };
 
 // Host-visible copy of the per-iteration counters (pinned, mapped memory).  k_trace(it) publishes
 // {n_active[it], n_rays[it]} when it STARTS; the host sizes the grids of iteration it+2 from it
 // (counts never grow) and stops launching once a published n_active is zero -- no stream sync.
 struct MirrorEntry {
-    uint32_t n_active, n_rays, seq, pad;
+    uint32_t n_active, n_rays, seq, remaining;  // remaining: camera samples of the batch not yet generated (saturated)
 };
 
 struct ChunkDesc {
-    uint32_t n_pixels;     // pixels in this chunk (PB)
-    uint32_t n_samples;    // samples per pixel in this chunk (spc)
+    uint32_t n_pixels;     // pixels in this batch (PB)
+    uint32_t n_samples;    // samples per pixel in this batch
     uint32_t pixel_base;   // offset into pix_list
     uint32_t sample_base;  // first sample index
     uint32_t width, height;
@@ -88,20 +100,47 @@ RTD void wave_count(bool pred, unsigned long long* counter) {
 RTD DevStats* stat_shard(DevStats* stats) { return stats + (blockIdx.x & (kStatShards - 1)); }
 
 // ------------------------------------------------------------------ generate
+// k_plan (one thread): how many camera samples this lane starts now = free pool slots, limited by
+// what the batch still holds; reserves them from the shared batch counter and appends them to the
+// path list / ray queue of iteration `it`.  Also clears the ring entries of iteration it+2.
+__global__ void k_plan(Ctl* ctl, BatchCtl* batch, uint32_t it, uint32_t pool, unsigned long long batch_total,
+                       DevStats* stats) {
+    const uint32_t r = it % kRing;
+    const uint32_t live = ctl->n_active[r];
+    unsigned long long want = pool > live ? pool - live : 0u;
+    unsigned long long first = 0;
+    if (want) {
+        first = atomicAdd(&batch->next, want);
+        if (first >= batch_total)
+            want = 0;
+        else if (first + want > batch_total)
+            want = batch_total - first;
+    }
+    ctl->gen_count = (uint32_t)want;
+    ctl->gen_first = (uint32_t)first;
+    ctl->gen_slot = live;
+    ctl->gen_q = ctl->n_rays[r];
+    ctl->n_active[r] = live + (uint32_t)want;
+    ctl->n_rays[r] += (uint32_t)want;
+    const uint32_t z = (it + 2) % kRing;
+    ctl->n_active[z] = 0;
+    ctl->n_rays[z] = 0;
+    ctl->head[z] = 0;
+    if (want) {
+        atomicAdd(&stats->paths, want);
+        atomicAdd(&stats->r1, want);
+    }
+}
+
 // integrator.rs:357-366 + sampler.rs:606-613 + geometry.rs:177-190 (+ util.rs:105-113)
 __global__ __launch_bounds__(256) void k_generate(PathState st, rt_camera cam, ChunkDesc ck,
                                                   const uint32_t* __restrict__ pix_list, uint32_t* queue,
-                                                  Ctl* ctl, DevStats* stats) {
-    const uint32_t total = ck.n_pixels * ck.n_samples;
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot == 0) {
-        ctl->n_active[0] = total;
-        ctl->n_rays[0] = total;
-        atomicAdd(&stats->paths, (unsigned long long)total);
-        atomicAdd(&stats->r1, (unsigned long long)total);
-    }
-    if (slot >= total) return;
-    const uint32_t s_local = slot / ck.n_pixels, p_local = slot - s_local * ck.n_pixels;
+                                                  const Ctl* ctl) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= ctl->gen_count) return;
+    const uint32_t g = ctl->gen_first + idx;  // path index inside the batch = film staging slot
+    const uint32_t slot = ctl->gen_slot + idx;
+    const uint32_t s_local = g / ck.n_pixels, p_local = g - s_local * ck.n_pixels;
     const uint32_t pix = pix_list[ck.pixel_base + p_local];
     const uint32_t px = pix % ck.width, py = pix / ck.width;
     uint64_t rng = rng_init(ck.seed, (uint64_t)pix, (uint64_t)(ck.sample_base + s_local));
@@ -133,8 +172,8 @@ __global__ __launch_bounds__(256) void k_generate(PathState st, rt_camera cam, C
     st3(st.lx, st.ly, st.lz, slot, black());
     st.rng[slot] = rng;
     st.flags[slot] = 0u;
-    st.orig[slot] = slot;
-    queue[slot] = slot | (kRayExt << 30);
+    st.orig[slot] = g;
+    queue[ctl->gen_q + idx] = slot | (kRayExt << 30);
 }
 
 // --------------------------------------------------------------------- trace
@@ -157,12 +196,17 @@ struct TraceTune {
 
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_trace(DevScene sc, PathState st, const uint32_t* __restrict__ queue,
-                                               Ctl* ctl, int it, DevStats* stats, TraceTune tune,
-                                               MirrorEntry* mirror, uint32_t seq) {
+                                               Ctl* ctl, uint32_t it_abs, DevStats* stats, TraceTune tune,
+                                               MirrorEntry* mirror, uint32_t seq, const BatchCtl* batch,
+                                               unsigned long long batch_total) {
+    const uint32_t it = it_abs % kRing;
     const uint32_t n = ctl->n_rays[it];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned long long nx = batch->next;
+        const unsigned long long rem = nx >= batch_total ? 0ull : batch_total - nx;
         mirror[it].n_active = ctl->n_active[it];
         mirror[it].n_rays = n;
+        mirror[it].remaining = rem > 0xffffffffull ? 0xffffffffu : (uint32_t)rem;
         __hip_atomic_store(&mirror[it].seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // a block only joins the work-pulling loop if the queue can give it at least one batch:
@@ -284,9 +328,10 @@ __global__ __launch_bounds__(256) void k_intersect_batch(DevScene sc, const rt_r
 }
 
 // --------------------------------------------------------------------- shade
-__global__ __launch_bounds__(256, 3) void k_shade(DevScene sc, PathState in, PathState out, Ctl* ctl, int it,
+__global__ __launch_bounds__(256, 3) void k_shade(DevScene sc, PathState in, PathState out, Ctl* ctl, uint32_t it_abs,
                                                uint32_t max_depth, uint32_t* queue_out, double* lfx, double* lfy,
                                                double* lfz, DevStats* stats) {
+    const uint32_t it = it_abs % kRing, itn = (it_abs + 1) % kRing;
     const uint32_t n_active = ctl->n_active[it];
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     // whole block past the end: nothing to do (block-uniform exit: the block barriers below stay well-formed)
@@ -359,7 +404,7 @@ __global__ __launch_bounds__(256, 3) void k_shade(DevScene sc, PathState in, Pat
         __syncthreads();
         if (threadIdx.x == 0) {
             const uint32_t tot = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0];
-            s_base[0] = tot ? atomicAdd(&ctl->n_active[it + 1], tot) : 0u;
+            s_base[0] = tot ? atomicAdd(&ctl->n_active[itn], tot) : 0u;
         }
         __syncthreads();
         uint32_t off = s_base[0];
@@ -503,7 +548,7 @@ __global__ __launch_bounds__(256, 3) void k_shade(DevScene sc, PathState in, Pat
                 tv += s_cnt[w][0];
             }
             const uint32_t tot = te + tsd + tp;
-            s_base[1] = tot ? atomicAdd(&ctl->n_rays[it + 1], tot) : 0u;
+            s_base[1] = tot ? atomicAdd(&ctl->n_rays[itn], tot) : 0u;
             DevStats* sh = stat_shard(stats);
             if (te) atomicAdd(&sh->r1, (unsigned long long)te);
             if (tsd) atomicAdd(&sh->r2, (unsigned long long)tsd);
