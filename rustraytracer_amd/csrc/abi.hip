@@ -485,7 +485,10 @@ static int run_lane(RenderJob& job, int lane_id) {
     unsigned long long it = 0;
     for (; it < max_iters; it++) {
         if (job.abort.load()) return RT_ERR_HIP;
-        if (it >= 2) {
+        static const bool no_mirror = getenv("RT_NO_MIRROR") != nullptr;  // experiment: fixed iteration count
+        if (no_mirror) {
+            if (it > (unsigned long long)cfg->max_depth + 2) break;
+        } else if (it >= 2) {
             // counters published when k_trace(it-2) started; two iterations stay queued behind it
             volatile MirrorEntry* me = &ln.mirror_h[(it - 2) % kRing];
             const uint32_t want_seq = seq0 + (uint32_t)(it - 2);
@@ -529,11 +532,11 @@ static int run_lane(RenderJob& job, int lane_id) {
         const uint32_t seq = seq0 + (uint32_t)it;
         if (job.count_trav)
             hipLaunchKernelGGL(k_trace<true>, dim3(tblocks), dim3(256), 0, stream, job.s->dev, ln.st[it & 1],
-                               ln.queue[it & 1], ln.ctl, (uint32_t)it, c->stats, c->tune, ln.mirror_d, seq, c->batch,
+                               ln.queue[it & 1], ln.ctl, (uint32_t)it, c->stats, c->tune, no_mirror ? nullptr : ln.mirror_d, seq, c->batch,
                                job.batch_total);
         else
             hipLaunchKernelGGL(k_trace<false>, dim3(tblocks), dim3(256), 0, stream, job.s->dev, ln.st[it & 1],
-                               ln.queue[it & 1], ln.ctl, (uint32_t)it, c->stats, c->tune, ln.mirror_d, seq, c->batch,
+                               ln.queue[it & 1], ln.ctl, (uint32_t)it, c->stats, c->tune, no_mirror ? nullptr : ln.mirror_d, seq, c->batch,
                                job.batch_total);
         if (!no_ev) {
             LANE_TRY(hipEventRecord(b, stream));
@@ -729,6 +732,10 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
         stats->kernel_ms = kernel_ms;
         stats->trace_ms = trace_ms;
         stats->trace_launches = trace_launches;
+        stats->reserved[0] = shards[0].pad[0];  // diagnostics of the instrumented build (tail launches)
+        stats->reserved[1] = shards[0].pad[1];
+        stats->reserved[2] = shards[0].pad[2];
+        stats->reserved[3] = shards[0].pad[3] | (shards[0].pad[4] << 16) | (shards[0].pad[5] << 40);
     }
     return RT_OK;
 }

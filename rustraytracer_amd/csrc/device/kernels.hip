@@ -201,7 +201,8 @@ __global__ __launch_bounds__(256) void k_trace(DevScene sc, PathState st, const 
                                                unsigned long long batch_total) {
     const uint32_t it = it_abs % kRing;
     const uint32_t n = ctl->n_rays[it];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const unsigned long long t_start = COUNT ? wall_clock64() : 0ull;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && mirror) {
         const unsigned long long nx = batch->next;
         const unsigned long long rem = nx >= batch_total ? 0ull : batch_total - nx;
         mirror[it].n_active = ctl->n_active[it];
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(256) void k_trace(DevScene sc, PathState st, const 
     tv.done = true;
     tv.cur = 0;
     bool has_ray = false;
+    uint32_t ray_steps0 = 0;
     bool exhausted = false;  // wave-uniform: the queue and this wave's reservation have no more entries
     uint32_t slot_kind = 0;
     uint32_t res_next = 0, res_end = 0;  // wave-uniform: [res_next, res_end) is reserved for this wave
@@ -268,6 +270,7 @@ __global__ __launch_bounds__(256) void k_trace(DevScene sc, PathState st, const 
                     trav_init(tv, sc, o, d, tmin, kInf);
                     slot_kind = e;
                     has_ray = true;
+                    if (COUNT) ray_steps0 = tc.nodes + tc.tris + tc.others;
                 }
             }
         }
@@ -288,6 +291,12 @@ __global__ __launch_bounds__(256) void k_trace(DevScene sc, PathState st, const 
             if (at_leaf) leaf_step<COUNT>(tv, sc, ts, &tc);
         }
         if (has_ray && tv.done) {
+            if (COUNT) {  // diagnostic: longest traversal, and how many rays needed more than 64 / 256 steps
+                const uint32_t steps = tc.nodes + tc.tris + tc.others - ray_steps0;
+                atomicMax(&stats->pad[3], (unsigned long long)steps);
+                if (steps > 64u) atomicAdd(&stats->pad[4], 1ull);
+                if (steps > 256u) atomicAdd(&stats->pad[5], 1ull);
+            }
             const uint32_t slot = slot_kind & kSlotMask, kind = slot_kind >> 30;
             if (kind == kRayExt)
                 st.hit_prim[slot] = tv.best_prim;
@@ -299,6 +308,11 @@ __global__ __launch_bounds__(256) void k_trace(DevScene sc, PathState st, const 
         }
     }
     if (COUNT) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && n < 4096u) {  // diagnostic: in-kernel time of tail launches (10 ns ticks)
+            atomicAdd(&stats->pad[0], wall_clock64() - t_start);
+            atomicAdd(&stats->pad[1], 1ull);
+            atomicAdd(&stats->pad[2], (unsigned long long)n);
+        }
         DevStats* sh = stat_shard(stats);
         atomicAdd(&sh->nodes, (unsigned long long)tc.nodes);
         atomicAdd(&sh->tris, (unsigned long long)tc.tris);
