@@ -75,7 +75,7 @@ struct rt_context {
     uint32_t* pix_list = nullptr;
     size_t pix_capacity = 0;
     std::vector<hipEvent_t> events;
-    TraceTune tune{32, 8, 4, 128};
+    TraceTune tune{32, 4, 0, 128};
 };
 
 struct rt_scene {
@@ -170,9 +170,8 @@ int rt_context_create(const int* device_ids, int n_devices, rt_context** out) {
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     if (const char* e = getenv("RT_TRACE_REFILL")) c->tune.refill_lanes = std::min(64, std::max(1, atoi(e)));
-    if (const char* e = getenv("RT_TRACE_NODE_ROUNDS")) c->tune.node_rounds = std::max(1, atoi(e));
+    if (const char* e = getenv("RT_TRACE_NODE_BIAS")) c->tune.node_bias = std::max(1, atoi(e));
     if (const char* e = getenv("RT_TRACE_RESERVE")) c->tune.reserve = std::max(64, atoi(e) & ~63);
-    if (const char* e = getenv("RT_TRACE_LEAF_ROUNDS")) c->tune.leaf_rounds = std::max(1, atoi(e));
     if (const char* e = getenv("RT_LANES")) c->n_lanes = std::min(kLanes, std::max(1, atoi(e)));
     for (int i = 0; i < kLanes; i++) {
         Lane& ln = c->lanes[i];
@@ -732,6 +731,13 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
         stats->kernel_ms = kernel_ms;
         stats->trace_ms = trace_ms;
         stats->trace_launches = trace_launches;
+        if (getenv("RT_DIAG")) {
+            unsigned long long d[4] = {0, 0, 0, 0};
+            for (int i = 0; i < kStatShards; i++)
+                for (int q = 0; q < 4; q++) d[q] += shards[i].pad[8 + q];
+            fprintf(stderr, "[rt diag] node rounds %llu avg lanes %.1f | prim rounds %llu avg lanes %.1f\n", d[0],
+                    d[0] ? (double)d[1] / d[0] : 0.0, d[2], d[2] ? (double)d[3] / d[2] : 0.0);
+        }
         stats->reserved[0] = shards[0].pad[0];  // diagnostics of the instrumented build (tail launches)
         stats->reserved[1] = shards[0].pad[1];
         stats->reserved[2] = shards[0].pad[2];

@@ -183,14 +183,14 @@ __global__ __launch_bounds__(256) void k_generate(PathState st, rt_camera cam, C
 //     queue entries (__ballot/__popcll prefix) while the others keep their state.  Entries come from a
 //     per-wave reservation of tune.reserve entries, so the single queue head sees one atomic per
 //     reservation, not per refill (same-address atomics saturate near 88/us).
-//   * Each round runs up to tune.node_rounds node-only steps (as long as any lane sits on an internal
-//     node) and then up to tune.leaf_rounds single-primitive steps: the wave never executes the
-//     primitive code for the sake of one lane while the rest are walking the tree, and vice versa.
+//   * Every wave step is EITHER a node step OR a single-primitive step, whichever more lanes are
+//     waiting for (majority scheduling): the wave never runs the primitive code for the sake of a few
+//     lanes while the rest are walking the tree, and vice versa.
 // Every wave leaves the loop once the queue is exhausted and its own lanes are done.
 struct TraceTune {
     int refill_lanes;  // refill when at least this many lanes are idle (<= 64)
-    int node_rounds;   // max consecutive node-only steps per round
-    int leaf_rounds;   // max consecutive primitive steps per round
+    int node_bias;     // a node step runs when lanes_at_nodes * node_bias >= lanes_at_leaves * 4 (4 = plain majority)
+    int unused;
     int reserve;       // queue entries a wave reserves per atomic (refills are served from the reservation)
 };
 
@@ -224,6 +224,7 @@ __global__ __launch_bounds__(256) void k_trace(DevScene sc, PathState st, const 
     tv.cur = 0;
     bool has_ray = false;
     uint32_t ray_steps0 = 0;
+    uint32_t diag_rounds[4] = {0, 0, 0, 0};  // wave-uniform diagnostics (instrumented build only)
     bool exhausted = false;  // wave-uniform: the queue and this wave's reservation have no more entries
     uint32_t slot_kind = 0;
     uint32_t res_next = 0, res_end = 0;  // wave-uniform: [res_next, res_end) is reserved for this wave
@@ -278,16 +279,23 @@ __global__ __launch_bounds__(256) void k_trace(DevScene sc, PathState st, const 
             if (exhausted) break;
             continue;  // all lanes idle: the refill above ran and either found rays or set `exhausted`
         }
-#pragma unroll 1
-        for (int k = 0; k < tune.node_rounds; k++) {
-            const bool at_node = has_ray && !tv.done && tv.cur >= 0;
-            if (__ballot(at_node) == 0ull) break;
+        // majority scheduling: run the kind of step (node or primitive) that more lanes are waiting for;
+        // the minority waits, and becomes the majority as the others change phase.
+        const bool at_node = has_ray && !tv.done && tv.cur >= 0;
+        const bool at_leaf = has_ray && !tv.done && tv.cur < 0;
+        const unsigned long long mn = __ballot(at_node), ml = __ballot(at_leaf);
+        const int cn = __popcll(mn), cl = __popcll(ml);
+        if (cn * tune.node_bias >= cl * 4 && cn > 0) {
+            if (COUNT) {  // diagnostic: lanes busy per node round
+                diag_rounds[0]++;
+                diag_rounds[1] += (uint32_t)cn;
+            }
             if (at_node) node_step<COUNT>(tv, sc, ts, &tc);
-        }
-#pragma unroll 1
-        for (int k = 0; k < tune.leaf_rounds; k++) {
-            const bool at_leaf = has_ray && !tv.done && tv.cur < 0;
-            if (__ballot(at_leaf) == 0ull) break;
+        } else if (cl > 0) {
+            if (COUNT) {  // diagnostic: lanes busy per primitive round
+                diag_rounds[2]++;
+                diag_rounds[3] += (uint32_t)cl;
+            }
             if (at_leaf) leaf_step<COUNT>(tv, sc, ts, &tc);
         }
         if (has_ray && tv.done) {
@@ -314,6 +322,8 @@ __global__ __launch_bounds__(256) void k_trace(DevScene sc, PathState st, const 
             atomicAdd(&stats->pad[2], (unsigned long long)n);
         }
         DevStats* sh = stat_shard(stats);
+        if (lane == 0)
+            for (int q = 0; q < 4; q++) atomicAdd(&sh->pad[8 + q], (unsigned long long)diag_rounds[q]);
         atomicAdd(&sh->nodes, (unsigned long long)tc.nodes);
         atomicAdd(&sh->tris, (unsigned long long)tc.tris);
         atomicAdd(&sh->others, (unsigned long long)tc.others);

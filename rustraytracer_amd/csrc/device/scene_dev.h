@@ -79,7 +79,7 @@ constexpr uint32_t kSlotMask = 0x3fffffffu;
 
 struct DevStats {  // one shard = two 64-B lines; kStatShards shards, summed by the host
     unsigned long long paths, r1, r2, r3, vertices, nodes, tris, others;
-    unsigned long long pad[8];
+    unsigned long long pad[16];  // pad[0..11]: diagnostics of the instrumented build
 };
 constexpr int kStatShards = 64;
 
