@@ -40,9 +40,9 @@ WORKLOADS = {
 
 def algorithmic_bytes(st, info):
     """Bytes the traversal kernel requests (cache hits included), f64 parity layout:
-    64 B per BVH node fetched, 76 B per triangle tested (72 B vertices + 4 B id), 124 B per
-    sphere/rect record tested (120 B + 4 B id), 56 B per ray (24 B origin + 24 B dir/target +
-    4 B queue entry + 4 B result)."""
+    128 B per BVH4 node fetched, 76 B per triangle tested (72 B vertices + 4 B id), 52 B per
+    sphere/rect tested (48 B parameters in the leaf slot + 4 B id), 56 B per ray (24 B origin +
+    24 B dir/target + 4 B queue entry + 4 B result)."""
     rays = st.rays_extension + st.rays_shadow + st.rays_probe
     return (info["node_bytes"] * st.nodes_fetched + info["tri_bytes"] * st.tris_tested +
             info["other_bytes"] * st.others_tested + 56 * rays)

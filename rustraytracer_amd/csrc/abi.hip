@@ -344,7 +344,7 @@ int rt_scene_commit(rt_scene* s) {
     HIP_TRY(hipSetDevice(s->ctx->device));
     BvhOut bvh;
     build_bvh(s->prims.data(), s->prims.size(), bvh);
-    if (bvh.depth > (uint32_t)kMaxBvhDepth) return fail(RT_ERR_UNSUPPORTED, "BVH depth %u exceeds the traversal stack", bvh.depth);
+    if (bvh.depth + 1 > (uint32_t)kMaxBvhDepth) return fail(RT_ERR_UNSUPPORTED, "BVH depth %u exceeds the traversal stack", bvh.depth);
     // leaf-ordered triangle vertices + ids
     const size_t np = s->prims.size();
     std::vector<uint32_t> leaf_prim(np);
@@ -362,6 +362,10 @@ int rt_scene_commit(rt_scene* s) {
             leaf_prim[i] = id;
             n_tri++;
         } else {
+            // sphere / rect: parameters + {kind, transform index + 1} ride in the vertex slot (geom.h: leaf_step)
+            for (int a = 0; a < 5; a++) leaf_tri[i * 9 + a] = p.v[a];
+            const uint64_t meta = (uint64_t)(p.kind & 0xffu) | ((uint64_t)(uint32_t)(p.xform_index + 1) << 32);
+            std::memcpy(&leaf_tri[i * 9 + 5], &meta, 8);
             leaf_prim[i] = id | kLeafOther;
         }
     }
@@ -398,7 +402,7 @@ int rt_scene_commit(rt_scene* s) {
     s->info.bvh_depth = bvh.depth;
     s->info.node_bytes = sizeof(DevNode);
     s->info.tri_bytes = 9 * sizeof(double) + sizeof(uint32_t);
-    s->info.other_bytes = sizeof(rt_primitive) + sizeof(uint32_t);
+    s->info.other_bytes = 6 * sizeof(double) + sizeof(uint32_t);  // v[5] + meta in the leaf slot, + id
     s->committed = true;
     return RT_OK;
 }

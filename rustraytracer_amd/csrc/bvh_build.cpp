@@ -3,9 +3,11 @@
 // Replaces BvhNode::new (src/hittable.rs:637-752: one primitive per leaf, median
 // split on a random axis, O(N log^2 N)).  The reference's traversal is exhaustive,
 // so its topology never changes a result; we are free to build a
-// binned-SAH BVH2 with up to 4 primitives per leaf, child boxes stored in the
-// parent, nodes in depth-first order (children of hot top levels stay adjacent in
-// L2/Infinity Cache) and depth bounded for the traversal stack.
+// binned-SAH binary tree with up to 4 primitives per leaf and collapse it into a
+// 4-wide BVH (each node absorbs its larger-area grandchildren until it has four
+// children): child boxes stored in the parent, nodes in depth-first order (children
+// of hot top levels stay adjacent in L2/Infinity Cache), depth bounded for the
+// traversal stack.
 #include "bvh_build.h"
 
 #include <algorithm>
@@ -51,14 +53,20 @@ inline float f_up(double x) {
     return f;
 }
 
+struct BinNode {
+    Box box;
+    int32_t left = -1, right = -1;  // children (internal)
+    int32_t leaf_ref = 0;           // leaf: -1 - (first*8 + count-1)
+    bool is_leaf = false;
+};
+
 struct Builder {
     const rt_primitive* prims;
     std::vector<uint32_t> order;  // primitive ids, partitioned in place
     std::vector<double> cx, cy, cz;
-    std::vector<DevNode>& nodes;
-    uint32_t max_depth = 0;
+    std::vector<BinNode> bin;
 
-    Builder(const rt_primitive* p, size_t n, std::vector<DevNode>& out) : prims(p), nodes(out) {
+    Builder(const rt_primitive* p, size_t n) : prims(p) {
         order.resize(n);
         cx.resize(n);
         cy.resize(n);
@@ -69,6 +77,7 @@ struct Builder {
             cy[i] = 0.5 * (p[i].bbox_min[1] + p[i].bbox_max[1]);
             cz[i] = 0.5 * (p[i].bbox_min[2] + p[i].bbox_max[2]);
         }
+        bin.reserve(n);
     }
     double centroid(uint32_t id, int axis) const { return axis == 0 ? cx[id] : (axis == 1 ? cy[id] : cz[id]); }
 
@@ -79,12 +88,22 @@ struct Builder {
         return bx;
     }
 
-    // returns child ref; fills `bx` with the subtree bounds
-    int32_t build(size_t b, size_t e, uint32_t depth, Box& bx) {
-        max_depth = std::max(max_depth, depth);
-        bx = bounds(b, e);
+    // binary tree over order[b, e); returns the BinNode index
+    int32_t build(size_t b, size_t e, uint32_t depth) {
+        const int32_t me = (int32_t)bin.size();
+        bin.push_back(BinNode{});
+        bin[me].box = bounds(b, e);
         const size_t n = e - b;
-        if (n <= (size_t)kMaxLeafPrims) return -1 - (int32_t)(b * 8 + (n - 1));
+        // Spheres and rects are large, few and expensive to test: each gets a leaf of its own, so that the
+        // (4-at-once) box tests and the front-to-back order prune them instead of a leaf loop testing all.
+        bool any_other = false;
+        for (size_t i = b; i < e && n <= (size_t)kMaxLeafPrims; i++)
+            any_other = any_other || prims[order[i]].kind != RT_PRIM_TRIANGLE;
+        if (n <= (size_t)kMaxLeafPrims && (n == 1 || !any_other)) {
+            bin[me].is_leaf = true;
+            bin[me].leaf_ref = -1 - (int32_t)(b * 8 + (n - 1));
+            return me;
+        }
         // centroid bounds
         double cmn[3], cmx[3];
         for (int a = 0; a < 3; a++) {
@@ -99,7 +118,7 @@ struct Builder {
             }
         size_t mid = b;
         bool split_done = false;
-        if (depth < 32) {
+        if (depth < 18) {  // SAH above, object median below: total binary depth <= 18 + ceil(log2(N/4)) <= 40
             constexpr int NB = 16;
             double best_cost = std::numeric_limits<double>::infinity();
             int best_axis = -1, best_bin = -1;
@@ -170,21 +189,68 @@ struct Builder {
                 return a_ < b_ || (a_ == b_ && x < y);
             });
         }
+        const int32_t l = build(b, mid, depth + 1);
+        const int32_t r = build(mid, e, depth + 1);
+        bin[me].left = l;
+        bin[me].right = r;
+        return me;
+    }
+};
+
+// Collapse: a 4-wide node takes a binary node's two children and keeps replacing the internal child
+// of largest surface area by its own two children until it has four (or only leaves are left).
+struct Collapser {
+    const std::vector<BinNode>& bin;
+    std::vector<DevNode>& nodes;
+    uint32_t max_depth = 0;
+    Collapser(const std::vector<BinNode>& b, std::vector<DevNode>& n) : bin(b), nodes(n) {}
+
+    int32_t emit(int32_t bi, uint32_t depth) {  // bi is an internal binary node
+        max_depth = std::max(max_depth, depth);
+        int32_t kids[4];
+        int nk = 0;
+        kids[nk++] = bin[bi].left;
+        kids[nk++] = bin[bi].right;
+        while (nk < 4) {
+            int best = -1;
+            double best_area = -1.0;
+            for (int k = 0; k < nk; k++)
+                if (!bin[kids[k]].is_leaf) {
+                    double a = bin[kids[k]].box.half_area();
+                    if (a > best_area) {
+                        best_area = a;
+                        best = k;
+                    }
+                }
+            if (best < 0) break;
+            const int32_t c = kids[best];
+            kids[best] = bin[c].left;
+            kids[nk++] = bin[c].right;
+        }
         const int32_t me = (int32_t)nodes.size();
         nodes.push_back(DevNode{});
-        Box lb, rb;
-        const int32_t l = build(b, mid, depth + 1, lb);
-        const int32_t r = build(mid, e, depth + 1, rb);
-        DevNode& nd = nodes[me];
-        for (int a = 0; a < 3; a++) {
-            nd.lmin[a] = f_down(lb.mn[a]);
-            nd.lmax[a] = f_up(lb.mx[a]);
-            nd.rmin[a] = f_down(rb.mn[a]);
-            nd.rmax[a] = f_up(rb.mx[a]);
+        int32_t refs[4];
+        for (int k = 0; k < 4; k++) {
+            if (k >= nk)
+                refs[k] = kNoChild;
+            else if (bin[kids[k]].is_leaf)
+                refs[k] = bin[kids[k]].leaf_ref;
+            else
+                refs[k] = emit(kids[k], depth + 1);
         }
-        nd.left = l;
-        nd.right = r;
-        nd.pad0 = nd.pad1 = 0;
+        DevNode& nd = nodes[me];
+        for (int k = 0; k < 4; k++) {
+            nd.child[k] = refs[k];
+            nd.pad[k] = 0;
+            if (k < nk) {
+                const Box& bx = bin[kids[k]].box;
+                nd.lo_x[k] = f_down(bx.mn[0]); nd.lo_y[k] = f_down(bx.mn[1]); nd.lo_z[k] = f_down(bx.mn[2]);
+                nd.hi_x[k] = f_up(bx.mx[0]);   nd.hi_y[k] = f_up(bx.mx[1]);   nd.hi_z[k] = f_up(bx.mx[2]);
+            } else {
+                nd.lo_x[k] = nd.lo_y[k] = nd.lo_z[k] = 0.0f;
+                nd.hi_x[k] = nd.hi_y[k] = nd.hi_z[k] = 0.0f;
+            }
+        }
         return me;
     }
 };
@@ -196,24 +262,24 @@ void build_bvh(const rt_primitive* prims, size_t n, BvhOut& out) {
     out.order.clear();
     out.depth = 0;
     if (n == 0) return;
-    out.nodes.reserve(n);
-    Builder bd(prims, n, out.nodes);
-    Box bx;
-    int32_t root = bd.build(0, n, 0, bx);
-    if (root < 0) {
+    Builder bd(prims, n);
+    const int32_t root = bd.build(0, n, 0);
+    out.nodes.reserve(bd.bin.size() / 2 + 2);
+    if (bd.bin[root].is_leaf) {
         // the whole scene fits one leaf: wrap it so that node 0 is always internal
         DevNode nd{};
-        for (int a = 0; a < 3; a++) {
-            nd.lmin[a] = f_down(bx.mn[a]);
-            nd.lmax[a] = f_up(bx.mx[a]);
-            nd.rmin[a] = nd.rmax[a] = 0.0f;
-        }
-        nd.left = root;
-        nd.right = kNoChild;
+        const Box& bx = bd.bin[root].box;
+        nd.lo_x[0] = f_down(bx.mn[0]); nd.lo_y[0] = f_down(bx.mn[1]); nd.lo_z[0] = f_down(bx.mn[2]);
+        nd.hi_x[0] = f_up(bx.mx[0]);   nd.hi_y[0] = f_up(bx.mx[1]);   nd.hi_z[0] = f_up(bx.mx[2]);
+        nd.child[0] = bd.bin[root].leaf_ref;
+        nd.child[1] = nd.child[2] = nd.child[3] = kNoChild;
         out.nodes.push_back(nd);
+    } else {
+        Collapser col(bd.bin, out.nodes);
+        col.emit(root, 0);
+        out.depth = col.max_depth;
     }
     out.order = std::move(bd.order);
-    out.depth = bd.max_depth;
 }
 
 }  // namespace rtd

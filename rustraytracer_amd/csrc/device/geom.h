@@ -14,7 +14,9 @@
 // an ordered, pruned walk over our own BVH: the f64 slab test is monotone in the
 // box, so a parent box (a superset, rounded outward to f32) passes whenever the
 // leaf's f64 box does; pruning uses [tmin, best_t*(1+1e-9)] so rounding between
-// the box entry and the primitive's own t can never drop a closer hit.
+// the box entry and the primitive's own t can never drop a closer hit.  The tree is
+// 4-wide (scene_dev.h); the order in which equally valid subtrees are visited does
+// not matter for the result (closest t, ties by primitive index).
 #pragma once
 #include "dvec.h"
 #include "scene_dev.h"
@@ -246,23 +248,24 @@ RTD bool tri_record(const DevScene& sc, const rt_primitive& pr, D3 o, D3 dir, do
 }
 
 // -------------------------------------------------------------------- rects
-// intersects.rs:10-175.  Outputs t and the in-plane coordinates.
-RTD bool rect_core(const DevScene& sc, const rt_primitive& pr, D3 o, D3 dir, double t0, double t1, double& t,
-                   double& a, double& b, D3& to, D3& td) {
+// intersects.rs:10-175.  Outputs t and the in-plane coordinates.  Takes the raw parameters
+// (kind, v = a0,b0,a1,b1,k, transform index) so that the traversal can feed it from the leaf slot.
+RTD bool rect_core_v(const DevScene& sc, uint32_t kind, double a0, double b0, double a1, double b1, double k,
+                     int32_t xform_index, D3 o, D3 dir, double t0, double t1, double& t, double& a, double& b, D3& to,
+                     D3& td) {
     to = o;
     td = dir;
-    if (pr.xform_index >= 0) {  // Ray::transform (geometry.rs:231-235) with the stored inverse
-        const rt_xform& xf = sc.xforms[pr.xform_index];
+    if (xform_index >= 0) {  // Ray::transform (geometry.rs:231-235) with the stored inverse
+        const rt_xform& xf = sc.xforms[xform_index];
         td = xf_vector(xf.inv, dir);
         to = xf_point(xf.inv, o);
     }
-    double k = pr.v[4];
-    if (pr.kind == RT_PRIM_XY_RECT) {
+    if (kind == RT_PRIM_XY_RECT) {
         t = (k - to.z) / td.z;
         if (t < t0 || t > t1) return false;
         a = to.x + t * td.x;
         b = to.y + t * td.y;
-    } else if (pr.kind == RT_PRIM_XZ_RECT) {
+    } else if (kind == RT_PRIM_XZ_RECT) {
         t = (k - to.y) / td.y;
         if (t < t0 || t > t1) return false;
         a = to.x + t * td.x;
@@ -273,8 +276,13 @@ RTD bool rect_core(const DevScene& sc, const rt_primitive& pr, D3 o, D3 dir, dou
         a = to.y + t * td.y;
         b = to.z + t * td.z;
     }
-    if (a < pr.v[0] || b < pr.v[1] || a > pr.v[2] || b > pr.v[3]) return false;
+    if (a < a0 || b < b0 || a > a1 || b > b1) return false;
     return true;
+}
+RTD bool rect_core(const DevScene& sc, const rt_primitive& pr, D3 o, D3 dir, double t0, double t1, double& t,
+                   double& a, double& b, D3& to, D3& td) {
+    return rect_core_v(sc, pr.kind, pr.v[0], pr.v[1], pr.v[2], pr.v[3], pr.v[4], pr.xform_index, o, dir, t0, t1, t, a,
+                       b, to, td);
 }
 RTD bool rect_record(const DevScene& sc, const rt_primitive& pr, D3 o, D3 dir, double t0, double t1, HitRec& h) {
     double t, a, b;
@@ -306,9 +314,7 @@ RTD bool rect_record(const DevScene& sc, const rt_primitive& pr, D3 o, D3 dir, d
 
 // ------------------------------------------------------------------- sphere
 // intersects.rs:177-213
-RTD bool sphere_core(const rt_primitive& pr, D3 o, D3 dir, double tmin, double tmax, double& t) {
-    D3 center = d3(pr.v[0], pr.v[1], pr.v[2]);
-    double r = pr.v[3];
+RTD bool sphere_core_v(D3 center, double r, D3 o, D3 dir, double tmin, double tmax, double& t) {
     D3 diff = o - center;
     double a = dot(dir, dir);
     double b = dot(diff, dir);
@@ -328,6 +334,9 @@ RTD bool sphere_core(const rt_primitive& pr, D3 o, D3 dir, double tmin, double t
         return true;
     }
     return false;
+}
+RTD bool sphere_core(const rt_primitive& pr, D3 o, D3 dir, double tmin, double tmax, double& t) {
+    return sphere_core_v(d3(pr.v[0], pr.v[1], pr.v[2]), pr.v[3], o, dir, tmin, tmax, t);
 }
 // intersects.rs:216-258 (Q8)
 RTD bool sphere_record(const rt_primitive& pr, D3 o, D3 dir, double tmin, double tmax, HitRec& h) {
@@ -391,7 +400,7 @@ struct TravCount {
 // culled by their own slab tests).  Keeping the private part under ~256 B per lane matters: a larger
 // scratch frame makes every dispatch of the kernel pay a use-once scratch allocation (~0.1 ms).
 constexpr int kLdsStack = 16;
-constexpr int kOvfStack = kMaxBvhDepth + 2 - kLdsStack;
+constexpr int kOvfStack = 3 * kMaxBvhDepth + 2 - kLdsStack;  // a 4-wide node pushes up to three children
 struct TravStack {
     int2* lds;       // &lds_stack[0][threadIdx.x], stride = blockDim.x entries
     int lds_stride;  // threads per block
@@ -460,36 +469,52 @@ RTD void trav_pop(Trav& tv, TravStack& ts) {
     tv.done = true;
 }
 
-// One internal node: test both children (one 64-B fetch), descend into the nearer, push the farther.
+// One internal node: test its four children (one 128-B fetch), descend into the nearest hit and push
+// the others so that they pop nearest-first.
 template <bool COUNT>
 RTD void node_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
     const D3 o = tv.o, inv = tv.inv;
     const double lim = tv.best_prim >= 0 ? tv.best_t * (1.0 + 1e-9) : tv.tmax;
     const float4* np = reinterpret_cast<const float4*>(&sc.nodes[tv.cur]);
-    const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5];
+    const int4 ch = *reinterpret_cast<const int4*>(np + 6);
     if (COUNT) tc->nodes++;
-    const int32_t left = __float_as_int(n3.x), right = __float_as_int(n3.y);
-    double el = 0.0, er = 0.0;
-    const bool sl = slab((double)n0.x, (double)n0.y, (double)n0.z, (double)n0.w, (double)n1.x, (double)n1.y, o, inv,
-                         tv.tmin, lim, el);
-    const bool sr = slab((double)n1.z, (double)n1.w, (double)n2.x, (double)n2.y, (double)n2.z, (double)n2.w, o, inv,
-                         tv.tmin, lim, er);
-    const bool hl = sl && left != kNoChild, hr = sr && right != kNoChild;
+    double e0, e1, e2, e3;
+    const bool h0 = slab((double)lx.x, (double)ly.x, (double)lz.x, (double)hx.x, (double)hy.x, (double)hz.x, o, inv,
+                         tv.tmin, lim, e0) && ch.x != kNoChild;
+    const bool h1 = slab((double)lx.y, (double)ly.y, (double)lz.y, (double)hx.y, (double)hy.y, (double)hz.y, o, inv,
+                         tv.tmin, lim, e1) && ch.y != kNoChild;
+    const bool h2 = slab((double)lx.z, (double)ly.z, (double)lz.z, (double)hx.z, (double)hy.z, (double)hz.z, o, inv,
+                         tv.tmin, lim, e2) && ch.z != kNoChild;
+    const bool h3 = slab((double)lx.w, (double)ly.w, (double)lz.w, (double)hx.w, (double)hy.w, (double)hz.w, o, inv,
+                         tv.tmin, lim, e3) && ch.w != kNoChild;
     tv.leaf_i = 0;
-    if (hl && hr) {
-        const bool swap = er < el;
-        const int32_t nearc = swap ? right : left, farc = swap ? left : right;
-        const double ef = swap ? el : er;
-        stack_push(ts, tv.sp, farc, float_lower(ef));
-        tv.sp++;
-        tv.cur = nearc;
-    } else if (hl) {
-        tv.cur = left;
-    } else if (hr) {
-        tv.cur = right;
-    } else {
-        trav_pop(tv, ts);
+    // sort the hit children by entry distance (misses sink to the end as +inf): 5-comparator network
+    const float kMiss = __builtin_huge_valf();
+    float d0 = h0 ? float_lower(e0) : kMiss, d1 = h1 ? float_lower(e1) : kMiss;
+    float d2 = h2 ? float_lower(e2) : kMiss, d3 = h3 ? float_lower(e3) : kMiss;
+    int32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
+#define RT_CSWAP(da, ca, db, cb)          \
+    if (db < da) {                         \
+        const float td_ = da; da = db; db = td_; \
+        const int32_t tc_ = ca; ca = cb; cb = tc_; \
     }
+    RT_CSWAP(d0, c0, d1, c1)
+    RT_CSWAP(d2, c2, d3, c3)
+    RT_CSWAP(d0, c0, d2, c2)
+    RT_CSWAP(d1, c1, d3, c3)
+    RT_CSWAP(d1, c1, d2, c2)
+#undef RT_CSWAP
+    const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+    if (nh == 0) {
+        trav_pop(tv, ts);
+        return;
+    }
+    // farthest first, so that the nearest pending child is on top of the stack
+    if (nh > 3) { stack_push(ts, tv.sp, c3, d3); tv.sp++; }
+    if (nh > 2) { stack_push(ts, tv.sp, c2, d2); tv.sp++; }
+    if (nh > 1) { stack_push(ts, tv.sp, c1, d1); tv.sp++; }
+    tv.cur = c0;
 }
 
 // One primitive of the current leaf (leaf code: -1 - (first*8 + count-1)); pops after the last one.
@@ -532,19 +557,43 @@ RTD void leaf_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
             }
         }
     } else {
+        // sphere / rect: the leaf slot carries v[0..4] and {kind, transform index} (abi.hip, commit), so an
+        // untransformed rect or a sphere needs no second, dependent fetch.  Their own AABB
+        // (Primitive::get_bounding_box) is re-derived with the constructor's arithmetic
+        // (primitive.rs:66-68, 110-113, 161-164, 212-215): k -/+ SMALL, centre -/+ r.
         pi = (int32_t)(e & ~kLeafOther);
-        const rt_primitive& pr = sc.prims[pi];
         if (COUNT) tc->others++;
+        const double v0 = q0.x, v1 = q0.y, v2 = q1.x, v3 = q1.y, v4 = q2.x;
+        const uint64_t meta = dm_bits(q2.y);
+        const uint32_t kind = (uint32_t)(meta & 0xffu);
+        const int32_t xform_index = (int32_t)(uint32_t)(meta >> 32) - 1;
+        double bx0, by0, bz0, bx1, by1, bz1;
+        if (xform_index >= 0) {  // transformed rect: its box is util::get_new_box's (util.rs:493-517), stored
+            const rt_primitive& pr = sc.prims[pi];
+            bx0 = pr.bbox_min[0]; by0 = pr.bbox_min[1]; bz0 = pr.bbox_min[2];
+            bx1 = pr.bbox_max[0]; by1 = pr.bbox_max[1]; bz1 = pr.bbox_max[2];
+        } else if (kind == RT_PRIM_SPHERE) {
+            bx0 = v0 - v3; by0 = v1 - v3; bz0 = v2 - v3;
+            bx1 = v0 + v3; by1 = v1 + v3; bz1 = v2 + v3;
+        } else if (kind == RT_PRIM_XY_RECT) {
+            bx0 = v0; by0 = v1; bz0 = v4 - kSmall;
+            bx1 = v2; by1 = v3; bz1 = v4 + kSmall;
+        } else if (kind == RT_PRIM_XZ_RECT) {
+            bx0 = v0; by0 = v4 - kSmall; bz0 = v1;
+            bx1 = v2; by1 = v4 + kSmall; bz1 = v3;
+        } else {
+            bx0 = v4 - kSmall; by0 = v0; bz0 = v1;
+            bx1 = v4 + kSmall; by1 = v2; bz1 = v3;
+        }
         double en;
-        if (slab(pr.bbox_min[0], pr.bbox_min[1], pr.bbox_min[2], pr.bbox_max[0], pr.bbox_max[1], pr.bbox_max[2], o, inv,
-                 tmin, tmax, en)) {
+        if (slab(bx0, by0, bz0, bx1, by1, bz1, o, inv, tmin, tmax, en)) {
             const D3 dir = d3(tv.trr.dir_x, tv.trr.dir_y, tv.trr.dir_z);
-            if (pr.kind == RT_PRIM_SPHERE) {
-                hit = sphere_core(pr, o, dir, tmin, tmax, t);
+            if (kind == RT_PRIM_SPHERE) {
+                hit = sphere_core_v(d3(v0, v1, v2), v3, o, dir, tmin, tmax, t);
             } else {
                 double a, b;
                 D3 to, td;
-                hit = rect_core(sc, pr, o, dir, tmin, tmax, t, a, b, to, td);
+                hit = rect_core_v(sc, kind, v0, v1, v2, v3, v4, xform_index, o, dir, tmin, tmax, t, a, b, to, td);
             }
         }
     }

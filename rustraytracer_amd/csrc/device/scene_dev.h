@@ -6,22 +6,24 @@
 
 namespace rtd {
 
-// BVH2 "fat" node, 64 B = one quarter of a 256-B HBM burst / half an L2 line:
-// both children's boxes live in the parent so one fetch decides both descents.
-// Boxes are f32 rounded OUTWARD from the f64 primitive boxes; the f64 slab test of
-// the reference (hittable.rs:494-508) is applied to them after an exact widen,
-// which keeps the test conservative (see geom.h).
+// BVH4 node, 128 B = exactly one L2 line / HBM burst pair: the four children's AABBs (f32, rounded
+// OUTWARD from the f64 primitive boxes, stored per axis so a lane reads them with eight 16-B loads)
+// and four child references.  One fetch decides four descents, which halves the length of the
+// dependent fetch chain of a ray compared with a binary tree -- the traversal is bound by memory
+// latency x outstanding requests, not by bytes or ALU.  The f64 slab test of
+// the reference (hittable.rs:494-508) is applied to the boxes after an exact widen, which keeps the
+// test conservative (see geom.h).
 struct DevNode {
-    float lmin[3], lmax[3];
-    float rmin[3], rmax[3];
-    int32_t left, right;  // >= 0: node index; kNoChild; else leaf: -1 - (first*8 + count-1)
-    int32_t pad0, pad1;
+    float lo_x[4], lo_y[4], lo_z[4];
+    float hi_x[4], hi_y[4], hi_z[4];
+    int32_t child[4];  // >= 0: node index; kNoChild; else leaf: -1 - (first*8 + count-1)
+    int32_t pad[4];
 };
-static_assert(sizeof(DevNode) == 64, "DevNode must be 64 bytes");
+static_assert(sizeof(DevNode) == 128, "DevNode must be 128 bytes");
 constexpr int32_t kNoChild = INT32_MIN;
 constexpr uint32_t kLeafOther = 0x80000000u;  // leaf entry is a sphere/rect, not a triangle
 constexpr int kMaxLeafPrims = 4;
-constexpr int kMaxBvhDepth = 54;  // traversal stack: 16 LDS + 40 private entries (geom.h)
+constexpr int kMaxBvhDepth = 24;  // of the 4-wide tree; traversal stack: 16 LDS + 58 private entries (geom.h)
 
 struct DevMesh {
     const double* p;
