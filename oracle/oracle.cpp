@@ -477,7 +477,7 @@ static bool bvh_exhaustive(const Scene& sc, int32_t ni, const Ray& ray, double t
 }
 
 // Same answer with pruning: a subtree is skipped when its box fails the
-// reference's own slab test against [tmin, best_t*(1+1e-9)] -- by monotonicity
+// reference's own slab test against [tmin, max(best_t, tmin)*(1+1e-9)] -- by monotonicity
 // of the slab arithmetic every ancestor box passes whenever the leaf box does.
 static bool bvh_ordered(const Scene& sc, const Ray& ray, double tmin, double tmax, Hit& out, Counters* c) {
     if (sc.root < 0) return false;
@@ -489,7 +489,9 @@ static bool bvh_ordered(const Scene& sc, const Ray& ray, double tmin, double tma
     while (sp > 0) {
         const BvhNode& n = sc.nodes[stack[--sp]];
         if (c) c->nodes++;
-        double lim = found ? out.t * (1.0 + 1e-9) : tmax;
+        // a triangle hit may lie below tmin (hittable.rs:360 accepts t >= 1e-4 whatever tmin is): the
+        // pruning interval [tmin, lim] must stay non-empty or a still closer such hit would be culled
+        double lim = found ? rmax(out.t * (1.0 + 1e-9), tmin * (1.0 + 1e-9) + 1e-300) : tmax;
         if (!box_intersects(n.bmin, n.bmax, ray, tmin, lim)) continue;
         if (n.prim >= 0) {
             // leaf: the reference tests the leaf box against the ORIGINAL interval
@@ -519,14 +521,39 @@ static bool brute_force(const Scene& sc, const Ray& ray, double tmin, double tma
     return found;
 }
 
-static bool closest_hit(const Scene& sc, int mode, const Ray& ray, double tmin, double tmax, Hit& out,
-                        Counters* c) {
+// optional per-thread log of every root closest-hit query (oracle_sample_rays)
+struct RayLog {
+    std::vector<rt_ray> rays;
+    std::vector<rt_hit> hits;
+};
+static thread_local RayLog* g_ray_log = nullptr;
+
+static bool closest_hit_impl(const Scene& sc, int mode, const Ray& ray, double tmin, double tmax, Hit& out,
+                             Counters* c) {
     if (mode == ORACLE_TRAVERSAL_EXHAUSTIVE) {
         if (sc.root < 0) return false;
         return bvh_exhaustive(sc, sc.root, ray, tmin, tmax, out, c);
     }
     if (mode == ORACLE_TRAVERSAL_BRUTE) return brute_force(sc, ray, tmin, tmax, out, c);
     return bvh_ordered(sc, ray, tmin, tmax, out, c);
+}
+static bool closest_hit(const Scene& sc, int mode, const Ray& ray, double tmin, double tmax, Hit& out,
+                        Counters* c) {
+    const bool found = closest_hit_impl(sc, mode, ray, tmin, tmax, out, c);
+    if (g_ray_log) {
+        rt_ray r;
+        r.origin[0] = ray.o.x; r.origin[1] = ray.o.y; r.origin[2] = ray.o.z;
+        r.dir[0] = ray.d.x; r.dir[1] = ray.d.y; r.dir[2] = ray.d.z;
+        r.tmin = tmin;
+        r.tmax = tmax;
+        rt_hit h;
+        h.t = found ? out.t : RT_INFINITY;
+        h.prim = found ? out.prim : -1;
+        h.reserved = 0;
+        g_ray_log->rays.push_back(r);
+        g_ray_log->hits.push_back(h);
+    }
+    return found;
 }
 
 // ------------------------------------------------------------- textures
@@ -1412,6 +1439,25 @@ int oracle_sample(const oracle_scene* s, const rt_camera* cam, const rt_render_c
         stats->vertices_shaded = cx.c.vertices;
     }
     return RT_OK;
+}
+
+// Every root closest-hit query (R1/R2/R3) of one camera sample, in program order, with its result.
+int64_t oracle_sample_rays(const oracle_scene* s, const rt_camera* cam, const rt_render_cfg* cfg, uint32_t px,
+                           uint32_t py, uint32_t sample, int traversal_mode, rt_ray* rays, rt_hit* hits,
+                           uint64_t capacity) {
+    if (!s || !cam || !cfg) return RT_ERR_INVALID_ARG;
+    RayLog log;
+    g_ray_log = &log;
+    Ctx cx{s->sc, traversal_mode, cfg->max_depth, Counters()};
+    Rng rng(cfg->seed, (uint64_t)py * cfg->width + px, sample);
+    (void)single_sample(cx, *cam, cfg->width, cfg->height, px, py, rng);
+    g_ray_log = nullptr;
+    const uint64_t n = std::min<uint64_t>(capacity, log.rays.size());
+    for (uint64_t i = 0; i < n; i++) {
+        if (rays) rays[i] = log.rays[i];
+        if (hits) hits[i] = log.hits[i];
+    }
+    return (int64_t)log.rays.size();
 }
 
 // ---- known-answer entry points

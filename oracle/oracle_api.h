@@ -37,6 +37,10 @@ int oracle_prim_intersect(const oracle_scene* s, int32_t prim, const rt_ray* ray
 int oracle_sample(const oracle_scene* s, const rt_camera* cam, const rt_render_cfg* cfg, uint32_t px, uint32_t py,
                   uint32_t sample, int traversal_mode, double* rgb, rt_stats* stats);
 
+int64_t oracle_sample_rays(const oracle_scene* s, const rt_camera* cam, const rt_render_cfg* cfg, uint32_t px,
+                           uint32_t py, uint32_t sample, int traversal_mode, rt_ray* rays, rt_hit* hits,
+                           uint64_t capacity);
+
 double oracle_fr_dielectric(double cos_theta_i, double eta_i, double eta_t);
 void oracle_fr_conductor(double cos_theta_i, const double* eta, const double* k, double* out);
 double oracle_power_heuristic(int nf, double f_pdf, int ng, double g_pdf);

@@ -13,8 +13,8 @@
 // passes the slab test on [tmin, 1e308]".  closest_hit() returns exactly that with
 // an ordered, pruned walk over our own BVH: the f64 slab test is monotone in the
 // box, so a parent box (a superset, rounded outward to f32) passes whenever the
-// leaf's f64 box does; pruning uses [tmin, best_t*(1+1e-9)] so rounding between
-// the box entry and the primitive's own t can never drop a closer hit.  The tree is
+// leaf's f64 box does; pruning uses [tmin, max(best_t, tmin)*(1+1e-9)] so rounding between
+// the box entry and the primitive's own t can never drop a closer hit (prune_limit()).  The tree is
 // 4-wide (scene_dev.h); the order in which equally valid subtrees are visited does
 // not matter for the result (closest t, ties by primitive index).
 #pragma once
@@ -452,9 +452,19 @@ RTD void trav_init(Trav& tv, const DevScene& sc, D3 o, D3 dir, double tmin, doub
     tv.done = false;
 }
 
+// Upper end of the interval a subtree's box must overlap to be worth visiting.  A triangle hit may lie
+// BELOW tmin (the reference's triangle test ignores tmin and accepts t >= 1e-4, hittable.rs:360, while
+// its boxes are tested on [tmin = 1e-3, ..), Q4), so the limit must never fall to tmin or below: the
+// interval [tmin, limit] has to stay non-empty or every remaining subtree -- including one holding a
+// still closer such hit -- would be culled.
+RTD double prune_limit(const Trav& tv) {
+    if (tv.best_prim < 0) return tv.tmax;
+    return hmax(tv.best_t * (1.0 + 1e-9), tv.tmin * (1.0 + 1e-9) + 1e-300);
+}
+
 // pop the next subtree that can still contain a closer hit; marks the traversal done when none is left
 RTD void trav_pop(Trav& tv, TravStack& ts) {
-    const double lim2 = tv.best_prim >= 0 ? tv.best_t * (1.0 + 1e-9) : tv.tmax;
+    const double lim2 = prune_limit(tv);
     while (tv.sp > 0) {
         tv.sp--;
         int32_t node;
@@ -474,7 +484,7 @@ RTD void trav_pop(Trav& tv, TravStack& ts) {
 template <bool COUNT>
 RTD void node_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
     const D3 o = tv.o, inv = tv.inv;
-    const double lim = tv.best_prim >= 0 ? tv.best_t * (1.0 + 1e-9) : tv.tmax;
+    const double lim = prune_limit(tv);
     const float4* np = reinterpret_cast<const float4*>(&sc.nodes[tv.cur]);
     const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5];
     const int4 ch = *reinterpret_cast<const int4*>(np + 6);

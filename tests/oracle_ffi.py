@@ -40,6 +40,9 @@ def lib():
     L.oracle_prim_intersect.argtypes = [vp, C.c_int32, C.POINTER(F.rt_ray), C.POINTER(oracle_hit_record)]
     L.oracle_sample.argtypes = [vp, C.POINTER(F.rt_camera), C.POINTER(F.rt_render_cfg), C.c_uint32, C.c_uint32,
                                 C.c_uint32, C.c_int, dp, C.POINTER(F.rt_stats)]
+    L.oracle_sample_rays.restype = C.c_int64
+    L.oracle_sample_rays.argtypes = [vp, C.POINTER(F.rt_camera), C.POINTER(F.rt_render_cfg), C.c_uint32, C.c_uint32,
+                                     C.c_uint32, C.c_int, C.POINTER(F.rt_ray), C.POINTER(F.rt_hit), C.c_uint64]
     L.oracle_fr_dielectric.restype = d
     L.oracle_fr_dielectric.argtypes = [d, d, d]
     L.oracle_fr_conductor.argtypes = [d, dp, dp, dp]
@@ -131,6 +134,16 @@ class OracleScene:
         rc = lib().oracle_sample(self._h, camera, C.byref(cfg), px, py, s, mode, rgb, C.byref(st))
         assert rc == 0
         return np.array(rgb[:]), st
+
+    def sample_rays(self, camera, cfg, px, py, s, mode=ORDERED, capacity=256):
+        """Every root closest-hit query of one camera sample: (origins, dirs, tmin, t, prim)."""
+        rays = (F.rt_ray * capacity)()
+        hits = (F.rt_hit * capacity)()
+        n = lib().oracle_sample_rays(self._h, camera, C.byref(cfg), px, py, s, mode, rays, hits, capacity)
+        assert 0 <= n <= capacity, n
+        ra = np.frombuffer(rays, dtype=np.float64).reshape(capacity, 8)[:n]
+        ha = np.frombuffer(hits, dtype=np.dtype([("t", "<f8"), ("prim", "<i4"), ("r", "<u4")]))[:n]
+        return ra[:, 0:3].copy(), ra[:, 3:6].copy(), ra[:, 6].copy(), ha["t"].copy(), ha["prim"].copy()
 
     def close(self):
         if self._h:

@@ -260,3 +260,43 @@ def test_abi_error_paths_on_device(gpu_ctx):
     assert L.rt_render(gpu_ctx._h, gs._h, sc.camera, C.byref(rr.make_cfg(16, 16, 2)), None, None, C.byref(st)) == 0
     assert st.paths == 16 * 16 * 2
     gs.close()
+
+
+def test_golden_rays_below_tmin(gpu_ctx):
+    """tests/golden/tmin_rays_dragon871k.json: the traversal must not prune hits with t < tmin (Q4)."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tmin_rays_dragon871k.json")))
+    sc = rr.Scene(g["scene"]["preset"], 1.0, g["scene"]["mesh_faces"], None, g["scene"]["variant"])
+    gs = gpu_ctx.upload(sc)
+    o = np.array([r["origin"] for r in g["rays"]])
+    d = np.array([r["dir"] for r in g["rays"]])
+    t, p = gpu_ctx.intersect_batch(gs, o, d, g["tmin"])
+    assert p.tolist() == [r["prim"] for r in g["rays"]]
+    assert [float(x).hex() for x in t] == [r["t_hex"] for r in g["rays"]]
+    gs.close()
+
+
+@pytest.mark.parametrize("case", [
+    ("plastic_dragon", 871414, 1, 768, 8),      # C3 scene (metal), full-size mesh
+    ("cornell_box_statue", 400000, 0, 512, 4),  # C2 scene, full-size mesh and image
+    ("plastic_dragon", 871414, 2, 384, 16),     # C5 scene (glass, deep paths)
+    ("two_dragons", 200000, 0, 384, 8),         # C4 scene
+], ids=["c3_metal", "c2_matte", "c5_glass", "c4_two_dragons"])
+def test_full_size_scenes_bit_identical(gpu_ctx, case):
+    """BASELINE-size meshes: film, sample counts and ray counters equal the oracle's exactly."""
+    preset, faces, variant, W, spp = case
+    sc = rr.Scene(preset, 1.0, faces, None, variant)
+    osc = O.OracleScene(sc)
+    gs = gpu_ctx.upload(sc)
+    cfg = rr.make_cfg(W, W, spp, seed=11)
+    ro, no, so = osc.render(sc.camera, cfg, O.ORDERED, threads=16)
+    rg, ng, sg = gpu_ctx.render(gs, sc.camera, cfg)
+    assert (sg.rays_extension, sg.rays_shadow, sg.rays_probe, sg.vertices_shaded) == \
+           (so.rays_extension, so.rays_shadow, so.rays_probe, so.vertices_shaded)
+    assert np.array_equal(ng, no)
+    finite = np.isfinite(ro)
+    assert np.array_equal(np.isfinite(rg), finite)
+    assert rmse(np.where(finite, rg, 0), ng, np.where(finite, ro, 0), no) < RMSE_TOL
+    assert np.array_equal(rg[finite], ro[finite])
+    gs.close()

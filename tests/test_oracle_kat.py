@@ -396,3 +396,20 @@ def test_emitted_light_and_cornell_statistics():
     right = img[24:40, 58:62].reshape(-1, 3).mean(0)
     assert left[1] > left[0] and left[1] > left[2]
     assert right[0] > right[1] and right[0] > right[2]
+
+
+def test_hits_below_tmin_are_not_pruned():
+    """Golden regression (tests/golden/tmin_rays_dragon871k.json): closest hits with 1e-4 <= t < tmin."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tmin_rays_dragon871k.json")))
+    sc = rr.Scene(g["scene"]["preset"], 1.0, g["scene"]["mesh_faces"], None, g["scene"]["variant"])
+    osc = O.OracleScene(sc)
+    o = np.array([r["origin"] for r in g["rays"]])
+    d = np.array([r["dir"] for r in g["rays"]])
+    want_t = np.array([float.fromhex(r["t_hex"]) for r in g["rays"]])
+    want_p = np.array([r["prim"] for r in g["rays"]])
+    assert (want_t < g["tmin"]).all() and (want_t >= 1e-4).all()
+    for mode in (O.ORDERED, O.EXHAUSTIVE):
+        t, p = osc.intersect_batch(o, d, g["tmin"], mode=mode)
+        assert np.array_equal(p, want_p) and np.array_equal(t, want_t), mode
