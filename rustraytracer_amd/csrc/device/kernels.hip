@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void k_intersect_batch(DevScene sc, const rt_r
 }
 
 // --------------------------------------------------------------------- shade
-__global__ __launch_bounds__(256, 3) void k_shade(DevScene sc, PathState in, PathState out, Ctl* ctl, uint32_t it_abs,
+__global__ __launch_bounds__(256, 2) void k_shade(DevScene sc, PathState in, PathState out, Ctl* ctl, uint32_t it_abs,
                                                uint32_t max_depth, uint32_t* queue_out, double* lfx, double* lfy,
                                                double* lfz, DevStats* stats) {
     const uint32_t it = it_abs % kRing, itn = (it_abs + 1) % kRing;
