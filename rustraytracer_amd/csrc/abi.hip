@@ -76,6 +76,7 @@ struct rt_context {
     size_t pix_capacity = 0;
     std::vector<hipEvent_t> events;
     TraceTune tune{32, 4, 0, 128};
+    uint32_t tail_paths = 131072;  // switch to the fused tail kernel at or below this many live paths
 };
 
 struct rt_scene {
@@ -172,6 +173,7 @@ int rt_context_create(const int* device_ids, int n_devices, rt_context** out) {
     if (const char* e = getenv("RT_TRACE_REFILL")) c->tune.refill_lanes = std::min(64, std::max(1, atoi(e)));
     if (const char* e = getenv("RT_TRACE_NODE_BIAS")) c->tune.node_bias = std::max(1, atoi(e));
     if (const char* e = getenv("RT_TRACE_RESERVE")) c->tune.reserve = std::max(64, atoi(e) & ~63);
+    if (const char* e = getenv("RT_TAIL_PATHS")) c->tail_paths = (uint32_t)std::max(0, atoi(e));
     if (const char* e = getenv("RT_LANES")) c->n_lanes = std::min(kLanes, std::max(1, atoi(e)));
     for (int i = 0; i < kLanes; i++) {
         Lane& ln = c->lanes[i];
@@ -512,6 +514,14 @@ static int run_lane(RenderJob& job, int lane_id) {
                 exhausted_known = true;
                 bound_active = std::min(bound_active, live);
                 if (live == 0) break;
+                if (live <= c->tail_paths) {
+                    // few paths left: one fused launch finishes them (k_tail) instead of ~2 launches per bounce
+                    // that are each as slow as their single longest ray
+                    hipLaunchKernelGGL(k_tail, dim3((live + 255) / 256), dim3(256), 0, stream, job.s->dev, ln.st[0],
+                                       ln.st[1], ln.ctl, (uint32_t)it, cfg->max_depth, c->lf[0], c->lf[1], c->lf[2],
+                                       c->stats);
+                    break;
+                }
             }
         }
         // top up the pool with new camera samples, then trace and shade everything alive

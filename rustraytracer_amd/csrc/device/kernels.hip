@@ -352,26 +352,29 @@ __global__ __launch_bounds__(256) void k_intersect_batch(DevScene sc, const rt_r
 }
 
 // --------------------------------------------------------------------- shade
-__global__ __launch_bounds__(256, 2) void k_shade(DevScene sc, PathState in, PathState out, Ctl* ctl, uint32_t it_abs,
-                                               uint32_t max_depth, uint32_t* queue_out, double* lfx, double* lfy,
-                                               double* lfz, DevStats* stats) {
-    const uint32_t it = it_abs % kRing, itn = (it_abs + 1) % kRing;
-    const uint32_t n_active = ctl->n_active[it];
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    // whole block past the end: nothing to do (block-uniform exit: the block barriers below stay well-formed)
-    if (blockIdx.x * blockDim.x >= n_active) return;
-    __shared__ uint32_t s_cnt[4][4];  // [wave][0 = output slots, 1..3 = ext / shadow / probe rays]
-    __shared__ uint32_t s_base[2];    // block's base in the next path list / ray queue
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const bool valid = slot < n_active;
-    const uint32_t fl = valid ? in.flags[slot] : kDead;
-    const bool live = valid && !(fl & kDead);
-    bool emit_ext = false, emit_sh = false, emit_pr = false, keep = false, shaded = false;
-    D3 L = black(), o = black();
-    if (live) {
-        L = ld3(in.lx, in.ly, in.lz, slot);
-        o = ld3(in.ox, in.oy, in.oz, slot);
-        // ---- fold the previous vertex's direct lighting (estimate_direct's two additions)
+// The per-vertex work, split where k_shade needs a block barrier (output-slot allocation):
+//   shade_a: fold the previous vertex's direct light (estimate_direct's two additions, using the R2/R3
+//            results), rebuild the record of the vertex the extension ray found, emitted-light rule.
+//   shade_b: BSDF, one-light NEE + MIS (integrator.rs:530-634), continuation sample, Russian roulette
+//            (integrator.rs:421-442); writes the survivor's state to slot `os` of `out`.
+// k_shade runs them for one bounce of every path; k_tail loops them per lane until the path retires.
+struct ShadeA {
+    D3 L, o, d, beta;
+    HitRec rec;
+    uint32_t fl, bounces;
+    bool live, spec, will_shade;
+};
+
+RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool valid, uint32_t max_depth, ShadeA& a) {
+    a.fl = valid ? in.flags[slot] : kDead;
+    const uint32_t fl = a.fl;
+    a.live = valid && !(fl & kDead);
+    a.L = black();
+    a.o = black();
+    if (a.live) {
+        a.L = ld3(in.lx, in.ly, in.lz, slot);
+        a.o = ld3(in.ox, in.oy, in.oz, slot);
+        // ---- fold the previous vertex's direct lighting
         if (fl & (kHasShadow | kHasProbe)) {
             const uint32_t light_idx = fl >> kLightShift;
             const rt_light& lt = sc.lights[light_idx];
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void k_shade(DevScene sc, PathState in, Pat
                     if (li >= 0 && (uint32_t)li == light_idx) {
                         const D3 pd = ld3(in.pdx, in.pdy, in.pdz, slot);
                         HitRec nh;
-                        if (prim_intersects(sc, pp, o, pd, kSmall, kInf, nh)) {
+                        if (prim_intersects(sc, pp, a.o, pd, kSmall, kInf, nh)) {
                             const D3 col = light_l(sc.lights[li], nh.n, -pd);  // new_record.le(-wi)
                             if (!is_black(col)) ld = ld + ld3(in.qx, in.qy, in.qz, slot);
                         }
@@ -394,36 +397,173 @@ __global__ __launch_bounds__(256, 2) void k_shade(DevScene sc, PathState in, Pat
                 }
             }
             const D3 bk = ld3(in.kx, in.ky, in.kz, slot);
-            L = L + cmul(ld * (double)sc.n_lights, bk);
+            a.L = a.L + cmul(ld * (double)sc.n_lights, bk);
         }
     }
     // ---- the vertex found by the extension ray
-    const bool active = live && !(fl & kFoldOnly);
-    int32_t hp = -1;
-    D3 d = black(), beta = black();
-    HitRec rec;
+    const bool active = a.live && !(fl & kFoldOnly);
+    a.d = black();
+    a.beta = black();
     bool is_some = false;
-    uint32_t bounces = fl & kBounceMask;
-    bool spec = (fl & kSpecular) != 0;
+    a.bounces = fl & kBounceMask;
+    a.spec = (fl & kSpecular) != 0;
     if (active) {
-        hp = in.hit_prim[slot];
-        d = ld3(in.dx, in.dy, in.dz, slot);
-        beta = ld3(in.bx, in.by, in.bz, slot);
+        const int32_t hp = in.hit_prim[slot];
+        a.d = ld3(in.dx, in.dy, in.dz, slot);
+        a.beta = ld3(in.bx, in.by, in.bz, slot);
         is_some = hp >= 0;
-        if (is_some) is_some = prim_intersects(sc, hp, o, d, kSmall, kInf, rec);
-        if (bounces == 0 || spec) {  // integrator.rs:396-411 (Q18)
+        if (is_some) is_some = prim_intersects(sc, hp, a.o, a.d, kSmall, kInf, a.rec);
+        if (a.bounces == 0 || a.spec) {  // integrator.rs:396-411 (Q18)
             if (is_some) {
-                const int32_t li = sc.prims[rec.prim].light_index;
-                if (li >= 0) L = L + cmul(light_l(sc.lights[li], rec.n, -d), beta);
+                const int32_t li = sc.prims[a.rec.prim].light_index;
+                if (li >= 0) a.L = a.L + cmul(light_l(sc.lights[li], a.rec.n, -a.d), a.beta);
             }
         }
     }
-    // a vertex that will be shaded gets its output slot now (dense, wave-contiguous); if the path
+    a.will_shade = active && is_some && a.bounces < max_depth;
+}
+
+struct ShadeOut {
+    bool emit_ext, emit_sh, emit_pr, keep;
+};
+
+// Precondition: a.will_shade.  `os` = slot of `out` reserved for this vertex.
+RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& out, uint32_t slot, uint32_t os,
+                     ShadeA& a) {
+    const HitRec& rec = a.rec;
+    D3 beta = a.beta;
+    uint32_t bounces = a.bounces;
+    bool spec = a.spec;
+    uint64_t rng = in.rng[slot];
+    Bsdf bsdf;
+    compute_scattering(sc, rec, bsdf);
+    bool has_sh = false, has_pr = false;
+    uint32_t light_num = 0;
+    // ---- uniform_sample_one_light / estimate_direct (integrator.rs:530-634)
+    if (sc.n_lights > 0) {
+        const double pick = rng_next(rng);
+        light_num = (uint32_t)(pick * (double)sc.n_lights);
+        if (light_num > sc.n_lights - 1) light_num = sc.n_lights - 1;
+        const double ul0 = rng_next(rng), ul1 = rng_next(rng);
+        const double us0 = rng_next(rng), us1 = rng_next(rng);
+        const rt_light& lt = sc.lights[light_num];
+        const rt_primitive& lp = sc.prims[lt.prim_index];
+        const uint32_t nsf = RT_BSDF_ALL - RT_BSDF_SPECULAR;
+        const D3 ltcolor = d3(lt.color[0], lt.color[1], lt.color[2]);
+        D3 sp, sn;
+        double light_pdf;
+        sample_area(sc, lp, ul0, ul1, sp, sn, light_pdf);  // Primitive::sample (Q9)
+        const D3 wi_raw = sp - rec.p;
+        if (norm2(wi_raw) == 0.0) {
+            light_pdf = 0.0;
+        } else {
+            const D3 wn = normalize(wi_raw);
+            light_pdf = light_pdf * norm2(rec.p - sp) / absd(dot(sn, -wn));
+        }
+        D3 wi, color;
+        if (light_pdf == 0.0 || norm2(rec.p - sp) == 0.0) {
+            light_pdf = 0.0;
+            wi = black();
+            color = ltcolor;
+        } else {
+            wi = normalize(sp - rec.p);
+            color = light_l(lt, sn, -wi);
+        }
+        if (light_pdf > 0.0 && !is_black(color)) {
+            const D3 f = bsdf_f(bsdf, rec.wo, wi, nsf) * absd(dot(wi, rec.sh_n));
+            const double scattering_pdf = bsdf_pdf(bsdf, rec.wo, wi, nsf);
+            if (!is_black(f)) {
+                has_sh = true;
+                const double weight = power_heuristic(1, light_pdf, 1, scattering_pdf);
+                st3(out.ax, out.ay, out.az, os, cmul(f, color) * (weight / light_pdf));
+                st3(out.spx, out.spy, out.spz, os, sp);
+            }
+        }
+        {
+            D3 f2, wi2;
+            double spdf;
+            uint32_t sampled;
+            bsdf_sample_f(bsdf, rec.wo, us0, us1, nsf, rng, f2, wi2, spdf, sampled);
+            f2 = f2 * absd(dot(wi2, rec.sh_n));
+            if (!is_black(f2) && spdf > 0.0) {
+                double weight = 1.0;
+                bool go = true;
+                if ((sampled & RT_BSDF_SPECULAR) == 0) {
+                    const double lpdf = prim_pdf(sc, lp, rec.p, wi2);  // Light::pdf_li
+                    if (lpdf == 0.0)
+                        go = false;
+                    else
+                        weight = power_heuristic(1, spdf, 1, lpdf);
+                }
+                if (go) {
+                    has_pr = true;
+                    st3(out.qx, out.qy, out.qz, os, cmul(f2, ltcolor) * (weight / spdf));
+                    st3(out.pdx, out.pdy, out.pdz, os, wi2);
+                }
+            }
+        }
+        if (has_sh || has_pr) st3(out.kx, out.ky, out.kz, os, beta);
+    }
+    // ---- continuation (integrator.rs:421-442)
+    const D3 wo = -a.d;
+    const double u0 = rng_next(rng), u1 = rng_next(rng);
+    D3 f, wi;
+    double pdf;
+    uint32_t sflags;
+    bsdf_sample_f(bsdf, wo, u0, u1, RT_BSDF_ALL, rng, f, wi, pdf, sflags);
+    bool cont = !(is_black(f) || pdf == 0.0);
+    if (cont) {
+        beta = cmul(beta, f) * (absd(dot(wi, rec.sh_n)) / pdf);
+        spec = (sflags & RT_BSDF_SPECULAR) != 0;
+        if (bounces > 3) {
+            const double q = rmax(0.05, 1.0 - rmax(beta.x, rmax(beta.y, beta.z)));
+            if (rng_next(rng) < q)
+                cont = false;
+            else
+                beta = beta * (1.0 / (1.0 - q));
+        }
+        bounces = bounces + 1;
+    }
+    ShadeOut r;
+    r.emit_ext = cont;
+    r.emit_sh = has_sh;
+    r.emit_pr = has_pr;
+    r.keep = cont || has_sh || has_pr;
+    if (r.keep) {
+        st3(out.ox, out.oy, out.oz, os, rec.p);  // spawn_ray: origin = hit point (Q4)
+        st3(out.lx, out.ly, out.lz, os, a.L);
+        if (cont) {
+            st3(out.dx, out.dy, out.dz, os, wi);
+            st3(out.bx, out.by, out.bz, os, beta);
+            out.rng[os] = rng;
+        }
+        out.orig[os] = in.orig[slot];
+        out.flags[os] = (bounces & kBounceMask) | (spec ? kSpecular : 0u) | (cont ? 0u : kFoldOnly) |
+                        (has_sh ? kHasShadow : 0u) | (has_pr ? kHasProbe : 0u) | (light_num << kLightShift);
+    } else {
+        out.flags[os] = kDead;
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(256, 2) void k_shade(DevScene sc, PathState in, PathState out, Ctl* ctl, uint32_t it_abs,
+                                               uint32_t max_depth, uint32_t* queue_out, double* lfx, double* lfy,
+                                               double* lfz, DevStats* stats) {
+    const uint32_t it = it_abs % kRing, itn = (it_abs + 1) % kRing;
+    const uint32_t n_active = ctl->n_active[it];
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    // whole block past the end: nothing to do (block-uniform exit: the block barriers below stay well-formed)
+    if (blockIdx.x * blockDim.x >= n_active) return;
+    __shared__ uint32_t s_cnt[4][4];  // [wave][0 = output slots, 1..3 = ext / shadow / probe rays]
+    __shared__ uint32_t s_base[2];    // block's base in the next path list / ray queue
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    ShadeA a;
+    shade_a(sc, in, slot, slot < n_active, max_depth, a);
+    // a vertex that will be shaded gets its output slot now (dense, block-contiguous); if the path
     // then ends without pending light terms the slot is marked dead and skipped next bounce
-    const bool will_shade = active && is_some && bounces < max_depth;
     uint32_t os;
     {   // one atomic per block: wave counts -> LDS -> block base -> per-lane slot
-        const unsigned long long m = __ballot(will_shade);
+        const unsigned long long m = __ballot(a.will_shade);
         if (lane == 0) s_cnt[wave][0] = (uint32_t)__popcll(m);
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -435,127 +575,18 @@ __global__ __launch_bounds__(256, 2) void k_shade(DevScene sc, PathState in, Pat
         for (uint32_t w = 0; w < wave; w++) off += s_cnt[w][0];
         os = off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     }
-    if (will_shade) {
-        uint64_t rng = in.rng[slot];
-        Bsdf bsdf;
-        compute_scattering(sc, rec, bsdf);
-        shaded = true;
-        bool has_sh = false, has_pr = false;
-        uint32_t light_num = 0;
-        // ---- uniform_sample_one_light / estimate_direct (integrator.rs:530-634)
-        if (sc.n_lights > 0) {
-            const double pick = rng_next(rng);
-            light_num = (uint32_t)(pick * (double)sc.n_lights);
-            if (light_num > sc.n_lights - 1) light_num = sc.n_lights - 1;
-            const double ul0 = rng_next(rng), ul1 = rng_next(rng);
-            const double us0 = rng_next(rng), us1 = rng_next(rng);
-            const rt_light& lt = sc.lights[light_num];
-            const rt_primitive& lp = sc.prims[lt.prim_index];
-            const uint32_t nsf = RT_BSDF_ALL - RT_BSDF_SPECULAR;
-            const D3 ltcolor = d3(lt.color[0], lt.color[1], lt.color[2]);
-            D3 sp, sn;
-            double light_pdf;
-            sample_area(sc, lp, ul0, ul1, sp, sn, light_pdf);  // Primitive::sample (Q9)
-            const D3 wi_raw = sp - rec.p;
-            if (norm2(wi_raw) == 0.0) {
-                light_pdf = 0.0;
-            } else {
-                const D3 wn = normalize(wi_raw);
-                light_pdf = light_pdf * norm2(rec.p - sp) / absd(dot(sn, -wn));
-            }
-            D3 wi, color;
-            if (light_pdf == 0.0 || norm2(rec.p - sp) == 0.0) {
-                light_pdf = 0.0;
-                wi = black();
-                color = ltcolor;
-            } else {
-                wi = normalize(sp - rec.p);
-                color = light_l(lt, sn, -wi);
-            }
-            if (light_pdf > 0.0 && !is_black(color)) {
-                const D3 f = bsdf_f(bsdf, rec.wo, wi, nsf) * absd(dot(wi, rec.sh_n));
-                const double scattering_pdf = bsdf_pdf(bsdf, rec.wo, wi, nsf);
-                if (!is_black(f)) {
-                    has_sh = true;
-                    const double weight = power_heuristic(1, light_pdf, 1, scattering_pdf);
-                    st3(out.ax, out.ay, out.az, os, cmul(f, color) * (weight / light_pdf));
-                    st3(out.spx, out.spy, out.spz, os, sp);
-                }
-            }
-            {
-                D3 f2, wi2;
-                double spdf;
-                uint32_t sampled;
-                bsdf_sample_f(bsdf, rec.wo, us0, us1, nsf, rng, f2, wi2, spdf, sampled);
-                f2 = f2 * absd(dot(wi2, rec.sh_n));
-                if (!is_black(f2) && spdf > 0.0) {
-                    double weight = 1.0;
-                    bool go = true;
-                    if ((sampled & RT_BSDF_SPECULAR) == 0) {
-                        const double lpdf = prim_pdf(sc, lp, rec.p, wi2);  // Light::pdf_li
-                        if (lpdf == 0.0)
-                            go = false;
-                        else
-                            weight = power_heuristic(1, spdf, 1, lpdf);
-                    }
-                    if (go) {
-                        has_pr = true;
-                        st3(out.qx, out.qy, out.qz, os, cmul(f2, ltcolor) * (weight / spdf));
-                        st3(out.pdx, out.pdy, out.pdz, os, wi2);
-                    }
-                }
-            }
-            if (has_sh || has_pr) st3(out.kx, out.ky, out.kz, os, beta);
-        }
-        // ---- continuation (integrator.rs:421-442)
-        const D3 wo = -d;
-        const double u0 = rng_next(rng), u1 = rng_next(rng);
-        D3 f, wi;
-        double pdf;
-        uint32_t sflags;
-        bsdf_sample_f(bsdf, wo, u0, u1, RT_BSDF_ALL, rng, f, wi, pdf, sflags);
-        bool cont = !(is_black(f) || pdf == 0.0);
-        if (cont) {
-            beta = cmul(beta, f) * (absd(dot(wi, rec.sh_n)) / pdf);
-            spec = (sflags & RT_BSDF_SPECULAR) != 0;
-            if (bounces > 3) {
-                const double q = rmax(0.05, 1.0 - rmax(beta.x, rmax(beta.y, beta.z)));
-                if (rng_next(rng) < q)
-                    cont = false;
-                else
-                    beta = beta * (1.0 / (1.0 - q));
-            }
-            bounces = bounces + 1;
-        }
-        emit_ext = cont;
-        emit_sh = has_sh;
-        emit_pr = has_pr;
-        keep = cont || has_sh || has_pr;
-        if (keep) {
-            st3(out.ox, out.oy, out.oz, os, rec.p);  // spawn_ray: origin = hit point (Q4)
-            st3(out.lx, out.ly, out.lz, os, L);
-            if (cont) {
-                st3(out.dx, out.dy, out.dz, os, wi);
-                st3(out.bx, out.by, out.bz, os, beta);
-                out.rng[os] = rng;
-            }
-            out.orig[os] = in.orig[slot];
-            out.flags[os] = (bounces & kBounceMask) | (spec ? kSpecular : 0u) | (cont ? 0u : kFoldOnly) |
-                            (has_sh ? kHasShadow : 0u) | (has_pr ? kHasProbe : 0u) | (light_num << kLightShift);
-        } else {
-            out.flags[os] = kDead;
-        }
-    }
-    if (live && !keep) {  // retired: its radiance goes to the film staging slot of (pixel, sample)
+    ShadeOut r{false, false, false, false};
+    if (a.will_shade) r = shade_b(sc, in, out, slot, os, a);
+    if (a.live && !r.keep) {  // retired: its radiance goes to the film staging slot of (pixel, sample)
         const uint32_t og = in.orig[slot];
-        lfx[og] = L.x;
-        lfy[og] = L.y;
-        lfz[og] = L.z;
+        lfx[og] = a.L.x;
+        lfy[og] = a.L.y;
+        lfz[og] = a.L.z;
     }
     // ---- rays of the next bounce: one queue reservation per block, laid out wave by wave as
     // [extension][shadow][probe]; statistics: one atomic per block and counter, on this block's shard
     {
-        const unsigned long long me = __ballot(emit_ext), ms = __ballot(emit_sh), mp = __ballot(emit_pr);
+        const unsigned long long me = __ballot(r.emit_ext), ms = __ballot(r.emit_sh), mp = __ballot(r.emit_pr);
         const uint32_t ce = (uint32_t)__popcll(me), cs = (uint32_t)__popcll(ms), cp = (uint32_t)__popcll(mp);
         if (lane == 0) {
             s_cnt[wave][1] = ce;
@@ -583,10 +614,71 @@ __global__ __launch_bounds__(256, 2) void k_shade(DevScene sc, PathState in, Pat
         uint32_t off = s_base[1];
         for (uint32_t w = 0; w < wave; w++) off += s_cnt[w][1] + s_cnt[w][2] + s_cnt[w][3];
         const unsigned long long below = (1ull << lane) - 1ull;
-        if (emit_ext) queue_out[off + (uint32_t)__popcll(me & below)] = os | (kRayExt << 30);
-        if (emit_sh) queue_out[off + ce + (uint32_t)__popcll(ms & below)] = os | (kRayShadow << 30);
-        if (emit_pr) queue_out[off + ce + cs + (uint32_t)__popcll(mp & below)] = os | (kRayProbe << 30);
+        if (r.emit_ext) queue_out[off + (uint32_t)__popcll(me & below)] = os | (kRayExt << 30);
+        if (r.emit_sh) queue_out[off + ce + (uint32_t)__popcll(ms & below)] = os | (kRayShadow << 30);
+        if (r.emit_pr) queue_out[off + ce + cs + (uint32_t)__popcll(mp & below)] = os | (kRayProbe << 30);
     }
+}
+
+// ---------------------------------------------------------------------- tail
+// Once a lane's batch is exhausted and few paths are left, per-bounce launches are bound by the single
+// longest ray of each launch (a few hundred dependent fetches), times the remaining bounces.  k_tail
+// finishes those paths in ONE launch: each lane traces its own pending rays (shadow, probe, extension)
+// with the same closest_hit and shades with the same shade_a / shade_b, ping-ponging its slot between
+// the two state buffers, until its path retires.  Same arithmetic, same counters, no queues.
+__global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathState buf1, const Ctl* ctl,
+                                             uint32_t it_abs, uint32_t max_depth, double* lfx, double* lfy,
+                                             double* lfz, DevStats* stats) {
+    __shared__ int2 lds_stack[kLdsStack * 256];
+    const uint32_t n_active = ctl->n_active[it_abs % kRing];
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_active || sc.n_nodes == 0) return;
+    TravStack ts;
+    ts.lds = &lds_stack[threadIdx.x];
+    ts.lds_stride = 256;
+    TravCount tc{0, 0, 0};
+    unsigned long long n_r1 = 0, n_r2 = 0, n_r3 = 0, n_v = 0;
+    int cur = (int)(it_abs & 1u);
+    // every pass retires the path or advances it by one bounce: max_depth + 2 passes always suffice
+    for (uint32_t pass = 0; pass < max_depth + 3u; pass++) {
+        const PathState& in = cur ? buf1 : buf0;
+        const PathState& out = cur ? buf0 : buf1;
+        const uint32_t fl = in.flags[slot];
+        if (fl & kDead) break;
+        const D3 o = ld3(in.ox, in.oy, in.oz, slot);
+        double t;
+        if (fl & kHasShadow) {  // Visibility::unoccluded, hittable.rs:25-32
+            const D3 d = ld3(in.spx, in.spy, in.spz, slot) - o;
+            in.sh_prim[slot] = closest_hit<false>(sc, o + d * kSmall, d, 0.0, kInf, t, ts, &tc);
+        }
+        if (fl & kHasProbe)
+            in.pr_prim[slot] = closest_hit<false>(sc, o, ld3(in.pdx, in.pdy, in.pdz, slot), kSmall, kInf, t, ts, &tc);
+        if (!(fl & kFoldOnly))
+            in.hit_prim[slot] = closest_hit<false>(sc, o, ld3(in.dx, in.dy, in.dz, slot), kSmall, kInf, t, ts, &tc);
+        ShadeA a;
+        shade_a(sc, in, slot, true, max_depth, a);
+        ShadeOut r{false, false, false, false};
+        if (a.will_shade) {
+            r = shade_b(sc, in, out, slot, slot, a);
+            n_v++;
+        }
+        n_r1 += r.emit_ext ? 1u : 0u;
+        n_r2 += r.emit_sh ? 1u : 0u;
+        n_r3 += r.emit_pr ? 1u : 0u;
+        if (!r.keep) {
+            const uint32_t og = in.orig[slot];
+            lfx[og] = a.L.x;
+            lfy[og] = a.L.y;
+            lfz[og] = a.L.z;
+            break;
+        }
+        cur ^= 1;
+    }
+    DevStats* sh = stat_shard(stats);
+    if (n_r1) atomicAdd(&sh->r1, n_r1);
+    if (n_r2) atomicAdd(&sh->r2, n_r2);
+    if (n_r3) atomicAdd(&sh->r3, n_r3);
+    if (n_v) atomicAdd(&sh->vertices, n_v);
 }
 
 // ------------------------------------------------------------------- resolve
