@@ -3,7 +3,6 @@ import ctypes as C
 import math
 import os
 import re
-import subprocess
 
 import numpy as np
 import pytest
@@ -76,8 +75,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), name
     assert L.rt_abi_version() == 1
     # the shared object really contains gfx950 code
-    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", F.LIB_PATH], capture_output=True, text=True)
-    assert "gfx950" in out.stdout + out.stderr
+    assert b"amdgcn-amd-amdhsa--gfx950" in open(F.LIB_PATH, "rb").read()
 
 
 def test_struct_layouts_match_the_header():
