@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--paths-in-flight", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: dry run of the N>1 control flow with several ranks sharing one GPU (films gathered on the host)")
     args = ap.parse_args()
 
     import torch
@@ -108,10 +110,16 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback exists)")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
+    coll_dev = "cuda" if args.backend == "nccl" else "cpu"
 
     preset, kw, W, H, spp0, desc = WORKLOADS[args.workload]
     spp = spp0 * world  # weak scaling: N times the samples, tiles interleaved over ranks
@@ -123,13 +131,20 @@ def main():
     d_n = torch.zeros((H, W), dtype=torch.int32, device="cuda")
     cfg = rr.make_cfg(W, H, spp, seed=0, tile_rank=rank, tile_world=world, paths_in_flight=args.paths_in_flight)
     from rustraytracer_amd import dist as rd
-    gather = rd.FilmGather(W, H, "cuda") if world > 1 else None
+    gather = rd.FilmGather(W, H, coll_dev) if world > 1 else None
 
     def step():
         st = ctx.render_device(gs, scene.camera, cfg, d_rgb.data_ptr(), d_n.data_ptr())
         if gather is not None:
             # the path's only exchange step: each rank's own tiles go straight to rank 0 (RCCL over xGMI)
-            gather.gather(d_rgb, d_n)
+            if coll_dev == "cuda":
+                gather.gather(d_rgb, d_n)
+            else:  # gloo dry run: stage through the host
+                h_rgb, h_n = d_rgb.cpu(), d_n.cpu()
+                gather.gather(h_rgb, h_n)
+                if rank == 0:
+                    d_rgb.copy_(h_rgb)
+                    d_n.copy_(h_n)
         return st
 
     def barrier():
@@ -154,8 +169,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     # max over ranks of the elapsed time, sum of rays
-    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    rr_ = torch.tensor([float(rays)], dtype=torch.float64, device="cuda")
+    tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+    rr_ = torch.tensor([float(rays)], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(rr_, op=dist.ReduceOp.SUM)
@@ -175,7 +190,7 @@ def main():
         achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", f"trace_pmc_{args.workload}.json")
-        if os.path.exists(pmc):
+        if world == 1 and os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:

@@ -24,7 +24,10 @@
  *     below, drawn in the order of SURVEY.md section 3.3;
  *   - exact-t ties between two primitives are won by the larger prim index
  *     (the reference's own winner is run-to-run random, hittable.rs:604-616,
- *     645-652).
+ *     645-652);
+ *   - a ray with a NaN origin or direction component misses (in the reference it
+ *     passes every slab test, f64::min/max dropping NaN, and "hits" whichever
+ *     triangle its randomly built tree visits first).
  */
 #ifndef RT_ABI_H
 #define RT_ABI_H

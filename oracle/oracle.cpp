@@ -530,6 +530,11 @@ static thread_local RayLog* g_ray_log = nullptr;
 
 static bool closest_hit_impl(const Scene& sc, int mode, const Ray& ray, double tmin, double tmax, Hit& out,
                              Counters* c) {
+    // ABI rule (include/rt_abi.h): a ray with a NaN component misses.  In the reference such a ray passes
+    // every slab test (f64::min/max drop NaN) and "hits" whichever triangle its random tree visits first.
+    if (ray.o.x != ray.o.x || ray.o.y != ray.o.y || ray.o.z != ray.o.z || ray.d.x != ray.d.x || ray.d.y != ray.d.y ||
+        ray.d.z != ray.d.z)
+        return false;
     if (mode == ORACLE_TRAVERSAL_EXHAUSTIVE) {
         if (sc.root < 0) return false;
         return bvh_exhaustive(sc, sc.root, ray, tmin, tmax, out, c);

@@ -449,7 +449,10 @@ RTD void trav_init(Trav& tv, const DevScene& sc, D3 o, D3 dir, double tmin, doub
     tv.cur = 0;
     tv.sp = 0;
     tv.leaf_i = 0;
-    tv.done = false;
+    // A ray with a NaN component (Q17: NaNs are never filtered) passes every slab test and "hits" whatever
+    // triangle is visited first, i.e. the reference's answer depends on its random tree.  The ABI pins it:
+    // such a ray misses.
+    tv.done = (o.x != o.x) || (o.y != o.y) || (o.z != o.z) || (dir.x != dir.x) || (dir.y != dir.y) || (dir.z != dir.z);
 }
 
 // Upper end of the interval a subtree's box must overlap to be worth visiting.  A triangle hit may lie

@@ -92,6 +92,13 @@ def test_empty_and_tiny_scenes(gpu_ctx):
     to, po = osc.intersect_batch(o, d, F.RT_SMALL)
     assert np.array_equal(pg, po) and np.array_equal(tg, to)
     assert pg[0] == -1 and tg[0] == F.RT_INFINITY
+    # NaN rays miss (ABI rule), infinite / zero directions behave like the oracle
+    o = np.array([[0.0, 5.0, 0.0], [np.nan, 5.0, 0.0], [0.0, 5.0, 0.0], [0.0, 5.0, 0.0]])
+    d = np.array([[np.nan, -1.0, 0.0], [0.0, -1.0, 0.0], [0.0, -np.inf, 0.0], [0.0, 0.0, 0.0]])
+    tg, pg = gpu_ctx.intersect_batch(gs, o, d, F.RT_SMALL)
+    to, po = osc.intersect_batch(o, d, F.RT_SMALL)
+    assert pg[0] == -1 and pg[1] == -1
+    assert np.array_equal(pg, po) and np.array_equal(tg, to, equal_nan=True)
     # zero rays is a no-op
     t0, p0 = gpu_ctx.intersect_batch(gs, np.zeros((0, 3)), np.zeros((0, 3)), F.RT_SMALL)
     assert t0.size == 0 and p0.size == 0
