@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/refresh_<tag>/ (tools/refresh_profiles.sh) into the committed files under profiles/.
+
+  --stage TAG    (on the GPU box) derive profiles/trace_pmc_TAG.json from the PMC summary
+  --collect TAG --round rNN   (here) copy kernel stats / PMC summary / bench line into profiles/
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+import shutil
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def stage(tag):
+    src = os.path.join(ROOT, "gpurun_out", "refresh_" + tag, "pmc_summary.json")
+    d = json.load(open(src))
+    key = [k for k in d if k.startswith("rtd::k_trace")][0]
+    t = d[key]
+    n = t["calls"]
+    rd_raw = t["FETCH_SIZE"] * 1024 / n
+    wr = t["WRITE_SIZE"] * 1024 / n
+    out = {
+        "kernel": key, "workload": tag, "launches": n,
+        "FETCH_SIZE_KB_sum": t["FETCH_SIZE"], "WRITE_SIZE_KB_sum": t["WRITE_SIZE"],
+        "hbm_read_bytes_per_launch_raw": rd_raw,
+        "hbm_read_bytes_per_launch_corrected_x2": 2 * rd_raw,
+        "hbm_write_bytes_per_launch": wr,
+        "hbm_bytes_per_launch": 2 * rd_raw + wr,
+        "l2_hit_rate": t.get("l2_hit_rate"),
+        "note": "rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum / WRITE_SIZE TCC_MISS_sum TCC_REQ_sum in separate passes with "
+                "--kernel-trace only; read side doubled per the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md "
+                "(HBM section); Infinity-Cache hits are counted, not excluded",
+    }
+    json.dump(out, open(os.path.join(ROOT, "profiles", f"trace_pmc_{tag}.json"), "w"), indent=1)
+
+
+def collect(tag, rnd):
+    src = os.path.join(ROOT, "gpurun_out", "refresh_" + tag)
+    prof = os.path.join(ROOT, "profiles")
+    ks = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
+    assert ks, "no kernel_stats.csv"
+    shutil.copy(ks[0], os.path.join(prof, f"{rnd}_kernel_stats_{tag}.csv"))
+    shutil.copy(os.path.join(src, "pmc_summary.json"), os.path.join(prof, f"{rnd}_pmc_summary_{tag}.json"))
+    shutil.copy(os.path.join(src, "bench_full.json"), os.path.join(prof, f"{rnd}_bench_{tag}.json"))
+    shutil.copy(os.path.join(src, f"trace_pmc_{tag}.json"), os.path.join(prof, f"trace_pmc_{tag}.json"))
+    b = json.load(open(os.path.join(src, "bench_full.json")))
+    sb = json.load(open(os.path.join(src, "stats_bench.json")))
+    for r in csv.DictReader(open(ks[0])):
+        if "k_trace" in r["Name"]:
+            print("rocprof k_trace avg ms", float(r["AverageNs"]) / 1e6, "calls", r["Calls"],
+                  "| bench-under-rocprof avg_launch_ms", sb["roofline"]["avg_launch_ms"],
+                  "| plain bench avg_launch_ms", b["roofline"]["avg_launch_ms"])
+    print(json.dumps({k: b[k] for k in ("value", "ms_per_step", "roofline", "cpu_baseline")}, indent=1))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--stage")
+    ap.add_argument("--collect")
+    ap.add_argument("--round", default="r01")
+    a = ap.parse_args()
+    if a.stage:
+        stage(a.stage)
+    if a.collect:
+        collect(a.collect, a.round)
