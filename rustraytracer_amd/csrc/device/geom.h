@@ -430,6 +430,9 @@ RTD void stack_get(const TravStack& ts, int sp, int32_t& node, float& t) {
 //   cur <  0 (not done) at a leaf, leaf_i-th primitive next -> leaf_step()
 struct Trav {
     D3 o, inv;
+    // f32 constants of the conservative interior-node test (node_step): t = fma(plane, inv32, c),
+    // c = -(o * inv32) -/+ slack for the near / far plane
+    float ix, iy, iz, cnx, cny, cnz, cfx, cfy, cfz;
     TriRay trr;
     double tmin, tmax, best_t;
     int32_t best_prim, cur;
@@ -438,10 +441,40 @@ struct Trav {
     bool done;
 };
 
+// Interior-node boxes only cull: a primitive is gated by the f64 slab test of its OWN box in leaf_step
+// (the reference's semantics, hittable.rs:625), and every ancestor box contains that box, so an ancestor
+// test may be evaluated in any arithmetic as long as it never rejects an interval the f64 test of a
+// contained box accepts.  node_step does it in f32 with one fma per plane,
+//     t32 = fma(plane, inv32, c),   inv32 = f32(1/d),   c = f32(-(o * inv32) -/+ s)
+// against the f64 value t = (plane - o) * (1/d):
+//     |t32 - t| <= 2^-24 |t|   (inv32 vs 1/d, both terms use the same inv32)
+//                + 2^-24 |o inv32|   (rounding c)  + 2^-24 |t32|   (the fma's single rounding)
+// The absolute part is folded into c as s = 2^-21 |o inv32| (lower bound for the near plane, upper bound
+// for the far plane); the relative part is applied after the 3-axis max/min as 2^-21 |t| (the axis that
+// attains the max/min is the one whose error matters).  Both carry a >= 4x margin over the bound above
+// and over the f64 roundings of the reference expression.  NaNs (0 * inf when a direction component is
+// 0 or below f32 range) are dropped by min/max, which only widens the accepted interval.
+constexpr float kNodeSlack = 4.76837158203125e-07f;  // 2^-21
+RTD void node_consts(Trav& tv) {
+    tv.ix = (float)tv.inv.x;
+    tv.iy = (float)tv.inv.y;
+    tv.iz = (float)tv.inv.z;
+    const double ox = tv.o.x * (double)tv.ix, oy = tv.o.y * (double)tv.iy, oz = tv.o.z * (double)tv.iz;
+    const double sx = absd(ox) * (double)kNodeSlack, sy = absd(oy) * (double)kNodeSlack,
+                 sz = absd(oz) * (double)kNodeSlack;
+    tv.cnx = (float)(-ox - sx);
+    tv.cny = (float)(-oy - sy);
+    tv.cnz = (float)(-oz - sz);
+    tv.cfx = (float)(-ox + sx);
+    tv.cfy = (float)(-oy + sy);
+    tv.cfz = (float)(-oz + sz);
+}
+
 RTD void trav_init(Trav& tv, const DevScene& sc, D3 o, D3 dir, double tmin, double tmax) {
     tv.o = o;
     tv.inv = d3(1.0 / dir.x, 1.0 / dir.y, 1.0 / dir.z);
     tv.trr = tri_ray(dir);
+    node_consts(tv);
     tv.tmin = tmin;
     tv.tmax = tmax;
     tv.best_t = tmax;
@@ -486,26 +519,46 @@ RTD void trav_pop(Trav& tv, TravStack& ts) {
 // the others so that they pop nearest-first.
 template <bool COUNT>
 RTD void node_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
-    const D3 o = tv.o, inv = tv.inv;
-    const double lim = prune_limit(tv);
-    const float4* np = reinterpret_cast<const float4*>(&sc.nodes[tv.cur]);
-    const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5];
-    const int4 ch = *reinterpret_cast<const int4*>(np + 6);
+    // near / far plane rows of the node picked by the direction signs (rows: lo_x lo_y lo_z hi_x hi_y hi_z,
+    // 16 B each), so no per-value select is needed
+    const char* nb = reinterpret_cast<const char*>(&sc.nodes[tv.cur]);
+    const uint32_t kx = (__float_as_uint(tv.ix) >> 31) * 48u, ky = (__float_as_uint(tv.iy) >> 31) * 48u,
+                   kz = (__float_as_uint(tv.iz) >> 31) * 48u;
+    const float4 nx = *reinterpret_cast<const float4*>(nb + kx);
+    const float4 ny = *reinterpret_cast<const float4*>(nb + 16u + ky);
+    const float4 nz = *reinterpret_cast<const float4*>(nb + 32u + kz);
+    const float4 fx = *reinterpret_cast<const float4*>(nb + 48u - kx);
+    const float4 fy = *reinterpret_cast<const float4*>(nb + 64u - ky);
+    const float4 fz = *reinterpret_cast<const float4*>(nb + 80u - kz);
+    const int4 ch = *reinterpret_cast<const int4*>(nb + 96u);
     if (COUNT) tc->nodes++;
-    double e0, e1, e2, e3;
-    const bool h0 = slab((double)lx.x, (double)ly.x, (double)lz.x, (double)hx.x, (double)hy.x, (double)hz.x, o, inv,
-                         tv.tmin, lim, e0) && ch.x != kNoChild;
-    const bool h1 = slab((double)lx.y, (double)ly.y, (double)lz.y, (double)hx.y, (double)hy.y, (double)hz.y, o, inv,
-                         tv.tmin, lim, e1) && ch.y != kNoChild;
-    const bool h2 = slab((double)lx.z, (double)ly.z, (double)lz.z, (double)hx.z, (double)hy.z, (double)hz.z, o, inv,
-                         tv.tmin, lim, e2) && ch.z != kNoChild;
-    const bool h3 = slab((double)lx.w, (double)ly.w, (double)lz.w, (double)hx.w, (double)hy.w, (double)hz.w, o, inv,
-                         tv.tmin, lim, e3) && ch.w != kNoChild;
+    const float tmin32 = float_lower(tv.tmin);
+    const float tmax32 = (float)tv.tmax * (1.0f + kNodeSlack);
+    const float lim32 = (float)prune_limit(tv) * (1.0f + kNodeSlack);
+#define RT_NODE_CHILD(c, e, h, cid)                                                                    \
+    float e;                                                                                           \
+    bool h;                                                                                            \
+    {                                                                                                  \
+        const float m_ = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(nx.c, tv.ix, tv.cnx),          \
+                                                         __builtin_fmaf(ny.c, tv.iy, tv.cny)),         \
+                                         __builtin_fmaf(nz.c, tv.iz, tv.cnz));                         \
+        const float f_ = __builtin_fminf(__builtin_fminf(__builtin_fmaf(fx.c, tv.ix, tv.cfx),          \
+                                                         __builtin_fmaf(fy.c, tv.iy, tv.cfy)),         \
+                                         __builtin_fmaf(fz.c, tv.iz, tv.cfz));                         \
+        e = __builtin_fmaxf(__builtin_fmaf(-__builtin_fabsf(m_), kNodeSlack, m_), tmin32);             \
+        const float x_ = __builtin_fminf(__builtin_fmaf(__builtin_fabsf(f_), kNodeSlack, f_), tmax32); \
+        h = e <= x_ && e <= lim32 && cid != kNoChild;                                                  \
+    }
+    RT_NODE_CHILD(x, e0, h0, ch.x)
+    RT_NODE_CHILD(y, e1, h1, ch.y)
+    RT_NODE_CHILD(z, e2, h2, ch.z)
+    RT_NODE_CHILD(w, e3, h3, ch.w)
+#undef RT_NODE_CHILD
     tv.leaf_i = 0;
     // sort the hit children by entry distance (misses sink to the end as +inf): 5-comparator network
     const float kMiss = __builtin_huge_valf();
-    float d0 = h0 ? float_lower(e0) : kMiss, d1 = h1 ? float_lower(e1) : kMiss;
-    float d2 = h2 ? float_lower(e2) : kMiss, d3 = h3 ? float_lower(e3) : kMiss;
+    float d0 = h0 ? e0 : kMiss, d1 = h1 ? e1 : kMiss;
+    float d2 = h2 ? e2 : kMiss, d3 = h3 ? e3 : kMiss;
     int32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
 #define RT_CSWAP(da, ca, db, cb)          \
     if (db < da) {                         \
