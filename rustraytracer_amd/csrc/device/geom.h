@@ -399,7 +399,13 @@ struct TravCount {
 // a small private array that only keeps the node (popped unconditionally; its children are then
 // culled by their own slab tests).  Keeping the private part under ~256 B per lane matters: a larger
 // scratch frame makes every dispatch of the kernel pay a use-once scratch allocation (~0.1 ms).
-constexpr int kLdsStack = 16;
+#ifndef RT_LDS_STACK
+#define RT_LDS_STACK 16
+#endif
+#ifndef RT_TRACE_WAVES
+#define RT_TRACE_WAVES 4
+#endif
+constexpr int kLdsStack = RT_LDS_STACK;
 constexpr int kOvfStack = 3 * kMaxBvhDepth + 2 - kLdsStack;  // a 4-wide node pushes up to three children
 struct TravStack {
     int2* lds;       // &lds_stack[0][threadIdx.x], stride = blockDim.x entries
@@ -608,8 +614,10 @@ RTD void leaf_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
         if (COUNT) tc->tris++;
         // the reference tests the leaf's own f64 box on the ORIGINAL interval (hittable.rs:625)
         double en, b0, b1, b2;
-        hit = slab(rmin(p0.x, rmin(p1.x, p2.x)), rmin(p0.y, rmin(p1.y, p2.y)), rmin(p0.z, rmin(p1.z, p2.z)),
-                   rmax(p0.x, rmax(p1.x, p2.x)), rmax(p0.y, rmax(p1.y, p2.y)), rmax(p0.z, rmax(p1.z, p2.z)), o, inv,
+        // (hmin/hmax drop NaN like f64::min/max; only the sign of a zero bound can differ, which the slab
+        // test does not observe -- see slab())
+        hit = slab(hmin(p0.x, hmin(p1.x, p2.x)), hmin(p0.y, hmin(p1.y, p2.y)), hmin(p0.z, hmin(p1.z, p2.z)),
+                   hmax(p0.x, hmax(p1.x, p2.x)), hmax(p0.y, hmax(p1.y, p2.y)), hmax(p0.z, hmax(p1.z, p2.z)), o, inv,
                    tmin, tmax, en) &&
               tri_core(p0, p1, p2, o, tv.trr, tmax, t, b0, b1, b2);
         pi = (int32_t)e;

@@ -195,7 +195,7 @@ struct TraceTune {
 };
 
 template <bool COUNT>
-__global__ __launch_bounds__(256) void k_trace(DevScene sc, PathState st, const uint32_t* __restrict__ queue,
+__global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, PathState st, const uint32_t* __restrict__ queue,
                                                Ctl* ctl, uint32_t it_abs, DevStats* stats, TraceTune tune,
                                                MirrorEntry* mirror, uint32_t seq, const BatchCtl* batch,
                                                unsigned long long batch_total) {
