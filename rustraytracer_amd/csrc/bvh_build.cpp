@@ -56,7 +56,7 @@ inline float f_up(double x) {
 struct BinNode {
     Box box;
     int32_t left = -1, right = -1;  // children (internal)
-    int32_t leaf_ref = 0;           // leaf: -1 - (first*8 + count-1)
+    int32_t leaf_ref = 0;           // leaf: -1 - ((first*8 + count-1) | kLeafCodeOther?)
     bool is_leaf = false;
 };
 
@@ -101,7 +101,7 @@ struct Builder {
             any_other = any_other || prims[order[i]].kind != RT_PRIM_TRIANGLE;
         if (n <= (size_t)kMaxLeafPrims && (n == 1 || !any_other)) {
             bin[me].is_leaf = true;
-            bin[me].leaf_ref = -1 - (int32_t)(b * 8 + (n - 1));
+            bin[me].leaf_ref = -1 - (int32_t)((uint32_t)(b * 8 + (n - 1)) | (any_other ? kLeafCodeOther : 0u));
             return me;
         }
         // centroid bounds

@@ -110,9 +110,21 @@ RTD D3 permute(D3 v, const TriRay& r) {  // util.rs:195-201 with (kx,ky,kz) a cy
     if (r.kz == 0) return d3(v.y, v.z, v.x);
     return d3(v.z, v.x, v.y);
 }
+RTD D3 unpermute(D3 v, int kz) {  // inverse of permute()
+    if (kz == 2) return v;
+    if (kz == 0) return d3(v.z, v.x, v.y);
+    return d3(v.y, v.z, v.x);
+}
+// the test on vertices already translated to the ray origin and permuted (p - o is componentwise, so it
+// commutes with the permutation)
+RTD bool tri_core_t(D3 p0t, D3 p1t, D3 p2t, const TriRay& tr, double tmax, double& t, double& b0, double& b1,
+                    double& b2);
 RTD bool tri_core(D3 p0, D3 p1, D3 p2, D3 o, const TriRay& tr, double tmax, double& t, double& b0, double& b1,
                   double& b2) {
-    D3 p0t = permute(p0 - o, tr), p1t = permute(p1 - o, tr), p2t = permute(p2 - o, tr);
+    return tri_core_t(permute(p0 - o, tr), permute(p1 - o, tr), permute(p2 - o, tr), tr, tmax, t, b0, b1, b2);
+}
+RTD bool tri_core_t(D3 p0t, D3 p1t, D3 p2t, const TriRay& tr, double tmax, double& t, double& b0, double& b1,
+                    double& b2) {
     const double s_x = tr.s_x, s_y = tr.s_y, s_z = tr.s_z;
     p0t.x += s_x * p0t.z; p0t.y += s_y * p0t.z;
     p1t.x += s_x * p1t.z; p1t.y += s_y * p1t.z;
@@ -435,7 +447,7 @@ RTD void stack_get(const TravStack& ts, int sp, int32_t& node, float& t) {
 //   cur >= 0            at an internal node          -> node_step()
 //   cur <  0 (not done) at a leaf, leaf_i-th primitive next -> leaf_step()
 struct Trav {
-    D3 o, inv;
+    D3 op, ip;  // origin and 1/dir, PERMUTED to the triangle test's (kx, ky, kz) axis order
     // f32 constants of the conservative interior-node test (node_step): t = fma(plane, inv32, c),
     // c = -(o * inv32) -/+ slack for the near / far plane
     float ix, iy, iz, cnx, cny, cnz, cfx, cfy, cfz;
@@ -461,11 +473,11 @@ struct Trav {
 // and over the f64 roundings of the reference expression.  NaNs (0 * inf when a direction component is
 // 0 or below f32 range) are dropped by min/max, which only widens the accepted interval.
 constexpr float kNodeSlack = 4.76837158203125e-07f;  // 2^-21
-RTD void node_consts(Trav& tv) {
-    tv.ix = (float)tv.inv.x;
-    tv.iy = (float)tv.inv.y;
-    tv.iz = (float)tv.inv.z;
-    const double ox = tv.o.x * (double)tv.ix, oy = tv.o.y * (double)tv.iy, oz = tv.o.z * (double)tv.iz;
+RTD void node_consts(Trav& tv, D3 o, D3 inv) {
+    tv.ix = (float)inv.x;
+    tv.iy = (float)inv.y;
+    tv.iz = (float)inv.z;
+    const double ox = o.x * (double)tv.ix, oy = o.y * (double)tv.iy, oz = o.z * (double)tv.iz;
     const double sx = absd(ox) * (double)kNodeSlack, sy = absd(oy) * (double)kNodeSlack,
                  sz = absd(oz) * (double)kNodeSlack;
     tv.cnx = (float)(-ox - sx);
@@ -477,10 +489,11 @@ RTD void node_consts(Trav& tv) {
 }
 
 RTD void trav_init(Trav& tv, const DevScene& sc, D3 o, D3 dir, double tmin, double tmax) {
-    tv.o = o;
-    tv.inv = d3(1.0 / dir.x, 1.0 / dir.y, 1.0 / dir.z);
+    const D3 inv = d3(1.0 / dir.x, 1.0 / dir.y, 1.0 / dir.z);
     tv.trr = tri_ray(dir);
-    node_consts(tv);
+    tv.op = permute(o, tv.trr);
+    tv.ip = permute(inv, tv.trr);
+    node_consts(tv, o, inv);
     tv.tmin = tmin;
     tv.tmax = tmax;
     tv.best_t = tmax;
@@ -589,42 +602,53 @@ RTD void node_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
     tv.cur = c0;
 }
 
-// One primitive of the current leaf (leaf code: -1 - (first*8 + count-1)); pops after the last one.
-// Ties in t go to the larger prim index (ABI tie rule).
+// One primitive of the current leaf (leaf code: -1 - ((first*8 + count-1) | kLeafCodeOther?)); pops after
+// the last one.  Ties in t go to the larger prim index (ABI tie rule).
 template <bool COUNT>
 RTD void leaf_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
-    const D3 o = tv.o, inv = tv.inv;
     const double tmin = tv.tmin, tmax = tv.tmax;
     const uint32_t code = (uint32_t)(-1 - tv.cur);
-    const uint32_t first = code >> 3, count = (code & 7u) + 1u;
+    const uint32_t first = (code & ~kLeafCodeOther) >> 3, count = (code & 7u) + 1u;
     const uint32_t slot = first + tv.leaf_i;
     const uint32_t e = sc.leaf_prim[slot];
-    // the vertex slot address does not depend on `e`: its loads are issued beside the id load
     const double* tvp = sc.leaf_tri + (size_t)slot * 9;
-    const double2 q0 = *reinterpret_cast<const double2*>(tvp);
-    const double2 q1 = *reinterpret_cast<const double2*>(tvp + 2);
-    const double2 q2 = *reinterpret_cast<const double2*>(tvp + 4);
-    const double2 q3 = *reinterpret_cast<const double2*>(tvp + 6);
-    const double q4 = tvp[8];
     double t = 0.0;
     int32_t pi = -1;
     bool hit = false;
-    if (!(e & kLeafOther)) {
-        const D3 p0 = d3(q0.x, q0.y, q1.x), p1 = d3(q1.y, q2.x, q2.y), p2 = d3(q3.x, q3.y, q4);
+    if (!(code & kLeafCodeOther)) {
+        // The nine coordinates are fetched in the ray's permuted axis order (kx, ky, kz), so the sheared
+        // test needs no per-triangle shuffle; the addresses do not depend on `e` (loads issue together).
+        const int kz = tv.trr.kz, kx = kz == 2 ? 0 : kz + 1, ky = kx == 2 ? 0 : kx + 1;
+        const double* px = tvp + kx;
+        const double* py = tvp + ky;
+        const double* pz = tvp + kz;
+        const D3 op = tv.op, ip = tv.ip;
         if (COUNT) tc->tris++;
-        // the reference tests the leaf's own f64 box on the ORIGINAL interval (hittable.rs:625)
-        double en, b0, b1, b2;
-        // (hmin/hmax drop NaN like f64::min/max; only the sign of a zero bound can differ, which the slab
-        // test does not observe -- see slab())
-        hit = slab(hmin(p0.x, hmin(p1.x, p2.x)), hmin(p0.y, hmin(p1.y, p2.y)), hmin(p0.z, hmin(p1.z, p2.z)),
-                   hmax(p0.x, hmax(p1.x, p2.x)), hmax(p0.y, hmax(p1.y, p2.y)), hmax(p0.z, hmax(p1.z, p2.z)), o, inv,
-                   tmin, tmax, en) &&
-              tri_core(p0, p1, p2, o, tv.trr, tmax, t, b0, b1, b2);
+        const D3 p0t = d3(px[0] - op.x, py[0] - op.y, pz[0] - op.z);
+        const D3 p1t = d3(px[3] - op.x, py[3] - op.y, pz[3] - op.z);
+        const D3 p2t = d3(px[6] - op.x, py[6] - op.y, pz[6] - op.z);
+        // The reference tests the leaf's own f64 box on the ORIGINAL interval (hittable.rs:625):
+        // ((min_i p_i) - o) * inv.  fl(a - o) is monotone in a, so min/max commute with the subtraction
+        // and the corner offsets are the min/max of the translated vertices (bit-identical); the axis order
+        // of the three slabs does not matter (max/min of the same six products).  hmin/hmax: see slab().
+        double lo = hmin(p0t.x, hmin(p1t.x, p2t.x)) * ip.x, hi = hmax(p0t.x, hmax(p1t.x, p2t.x)) * ip.x;
+        double tn = hmax(tmin, hmin(lo, hi)), tf = hmin(tmax, hmax(lo, hi));
+        lo = hmin(p0t.y, hmin(p1t.y, p2t.y)) * ip.y;
+        hi = hmax(p0t.y, hmax(p1t.y, p2t.y)) * ip.y;
+        tn = hmax(tn, hmin(lo, hi));
+        tf = hmin(tf, hmax(lo, hi));
+        lo = hmin(p0t.z, hmin(p1t.z, p2t.z)) * ip.z;
+        hi = hmax(p0t.z, hmax(p1t.z, p2t.z)) * ip.z;
+        tn = hmax(tn, hmin(lo, hi));
+        tf = hmin(tf, hmax(lo, hi));
+        double b0, b1, b2;
+        hit = !(tf <= tn) && tri_core_t(p0t, p1t, p2t, tv.trr, tmax, t, b0, b1, b2);
         pi = (int32_t)e;
         if (hit && sc.mesh_has_uv) {  // rare path: uv-degenerate rejection (hittable.rs:373-378)
             const rt_primitive& pr = sc.prims[pi];
             const DevMesh& m = sc.meshes[pr.mesh_index];
             if (m.uv) {
+                const D3 p0 = d3(tvp[0], tvp[1], tvp[2]), p1 = d3(tvp[3], tvp[4], tvp[5]), p2 = d3(tvp[6], tvp[7], tvp[8]);
                 TriUv uv = tri_uvs(m, m.ind[pr.tri_ind], m.ind[pr.tri_ind + 1], m.ind[pr.tri_ind + 2]);
                 D3 du, dv;
                 hit = tri_dpdu(p0, p1, p2, uv, du, dv);
@@ -635,6 +659,10 @@ RTD void leaf_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
         // untransformed rect or a sphere needs no second, dependent fetch.  Their own AABB
         // (Primitive::get_bounding_box) is re-derived with the constructor's arithmetic
         // (primitive.rs:66-68, 110-113, 161-164, 212-215): k -/+ SMALL, centre -/+ r.
+        const double2 q0 = *reinterpret_cast<const double2*>(tvp);
+        const double2 q1 = *reinterpret_cast<const double2*>(tvp + 2);
+        const double2 q2 = *reinterpret_cast<const double2*>(tvp + 4);
+        const D3 o = unpermute(tv.op, tv.trr.kz), inv = unpermute(tv.ip, tv.trr.kz);
         pi = (int32_t)(e & ~kLeafOther);
         if (COUNT) tc->others++;
         const double v0 = q0.x, v1 = q0.y, v2 = q1.x, v3 = q1.y, v4 = q2.x;

@@ -16,12 +16,13 @@ namespace rtd {
 struct DevNode {
     float lo_x[4], lo_y[4], lo_z[4];
     float hi_x[4], hi_y[4], hi_z[4];
-    int32_t child[4];  // >= 0: node index; kNoChild; else leaf: -1 - (first*8 + count-1)
+    int32_t child[4];  // >= 0: node index; kNoChild; else leaf: -1 - ((first*8 + count-1) | kLeafCodeOther?)
     int32_t pad[4];
 };
 static_assert(sizeof(DevNode) == 128, "DevNode must be 128 bytes");
 constexpr int32_t kNoChild = INT32_MIN;
 constexpr uint32_t kLeafOther = 0x80000000u;  // leaf entry is a sphere/rect, not a triangle
+constexpr uint32_t kLeafCodeOther = 1u << 30;  // leaf code flag: the leaf holds one sphere/rect (they never share a leaf)
 constexpr int kMaxLeafPrims = 4;
 constexpr int kMaxBvhDepth = 24;  // of the 4-wide tree; traversal stack: 16 LDS + 58 private entries (geom.h)
 
