@@ -253,11 +253,24 @@ int rt_scene_set_lights(rt_scene* s, const rt_light* lights, uint64_t count);
 /* Validates indices, builds the BVH (replaces BvhNode::new,
  * hittable.rs:637-752) and uploads everything to HBM.                         */
 int rt_scene_commit(rt_scene* s);
+/* Next-row f3: choose the BVH builder.  Both produce the same device layout and,
+ * because a primitive is gated only by the f64 test of its own box, the same
+ * film bit for bit; they differ in build time and traversal cost.
+ *   RT_COMMIT_HOST_SAH     binned SAH on the host (default, best tree)
+ *   RT_COMMIT_DEVICE_LBVH  Morton-order linear BVH built on the GPU from the
+ *                          uploaded primitives (milliseconds; for callers that
+ *                          re-commit geometry often)                            */
+#define RT_COMMIT_HOST_SAH 0u
+#define RT_COMMIT_DEVICE_LBVH 1u
+int rt_scene_commit_ex(rt_scene* s, uint32_t flags);
 int rt_scene_destroy(rt_scene* s);
 /* Sizes of the committed device layout, for roofline accounting.             */
 typedef struct rt_scene_info {
     uint64_t n_prims, n_triangles, n_others, n_bvh_nodes, bvh_depth;
     uint64_t node_bytes, tri_bytes, other_bytes, device_bytes_total;
+    uint64_t build_flags;    /* RT_COMMIT_* the scene was committed with          */
+    double build_ms;         /* BVH build + leaf layout + their upload, host clock */
+    double build_device_ms;  /* RT_COMMIT_DEVICE_LBVH: device time of the build   */
 } rt_scene_info;
 int rt_scene_get_info(const rt_scene* s, rt_scene_info* out);
 

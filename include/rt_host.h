@@ -35,6 +35,8 @@ int rrh_camera_new(const double* from, const double* to, const double* up, doubl
 
 /* rt_scene_create + set_* + commit in one call */
 int rrh_scene_upload(rt_context* ctx, const rt_scene_desc* desc, rt_scene** out);
+/* same with rt_scene_commit_ex flags (RT_COMMIT_DEVICE_LBVH: BVH built on the GPU) */
+int rrh_scene_upload_ex(rt_context* ctx, const rt_scene_desc* desc, uint32_t commit_flags, rt_scene** out);
 
 /* GPU sibling of render::tile_multithread (src/render.rs:13): whole image, one call */
 int rrh_gpu_tile(rt_context* ctx, rt_scene* scene, const rt_camera* camera, uint32_t width, uint32_t height,

@@ -23,6 +23,8 @@ RT_TEX_SOLID, RT_TEX_CHECKERED = 0, 1
 RT_MAT_MATTE, RT_MAT_LIGHT, RT_MAT_PLASTIC, RT_MAT_GLASS, RT_MAT_METAL, RT_MAT_MIRROR = range(6)
 RT_NO_TEXTURE = 0xFFFFFFFF
 RT_RENDER_COUNT_TRAVERSAL = 1
+RT_COMMIT_HOST_SAH = 0
+RT_COMMIT_DEVICE_LBVH = 1
 RT_INFINITY = 1e308
 RT_SMALL = 0.001
 
@@ -119,19 +121,20 @@ class rt_hit(C.Structure):
 class rt_scene_info(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in (
         "n_prims", "n_triangles", "n_others", "n_bvh_nodes", "bvh_depth", "node_bytes", "tri_bytes",
-        "other_bytes", "device_bytes_total")]
+        "other_bytes", "device_bytes_total", "build_flags")] + [("build_ms", C.c_double),
+                                                                     ("build_device_ms", C.c_double)]
 
 
 # every symbol include/rt_abi.h and include/rt_host.h declare
 ABI_SYMBOLS = [
     "rt_context_create", "rt_context_destroy", "rt_scene_create", "rt_scene_set_meshes",
     "rt_scene_set_primitives", "rt_scene_set_transforms", "rt_scene_set_materials", "rt_scene_set_textures",
-    "rt_scene_set_lights", "rt_scene_commit", "rt_scene_destroy", "rt_scene_get_info", "rt_render",
+    "rt_scene_set_lights", "rt_scene_commit", "rt_scene_commit_ex", "rt_scene_destroy", "rt_scene_get_info", "rt_render",
     "rt_render_device", "rt_intersect_batch", "rt_resolve_rgb8", "rt_last_error", "rt_abi_version",
 ]
 HOST_SYMBOLS = [
     "rrh_scene_build", "rrh_scene_destroy", "rrh_scene_desc", "rrh_scene_camera", "rrh_scene_name",
-    "rrh_last_error", "rrh_camera_new", "rrh_scene_upload", "rrh_gpu_tile",
+    "rrh_last_error", "rrh_camera_new", "rrh_scene_upload", "rrh_scene_upload_ex", "rrh_gpu_tile",
 ]
 
 _lib = None
@@ -163,6 +166,7 @@ def lib():
     L.rt_scene_set_textures.argtypes = [vp, C.POINTER(rt_texture), C.c_uint64]
     L.rt_scene_set_lights.argtypes = [vp, C.POINTER(rt_light), C.c_uint64]
     L.rt_scene_commit.argtypes = [vp]
+    L.rt_scene_commit_ex.argtypes = [vp, C.c_uint32]
     L.rt_scene_destroy.argtypes = [vp]
     L.rt_scene_get_info.argtypes = [vp, C.POINTER(rt_scene_info)]
     L.rt_render.argtypes = [vp, vp, C.POINTER(rt_camera), C.POINTER(rt_render_cfg), vp, vp, C.POINTER(rt_stats)]
@@ -178,6 +182,7 @@ def lib():
     L.rrh_scene_camera.argtypes = [vp]
     L.rrh_camera_new.argtypes = [C.POINTER(C.c_double)] * 3 + [C.c_double] * 6 + [C.POINTER(rt_camera)]
     L.rrh_scene_upload.argtypes = [vp, C.POINTER(rt_scene_desc), C.POINTER(vp)]
+    L.rrh_scene_upload_ex.argtypes = [vp, C.POINTER(rt_scene_desc), C.c_uint32, C.POINTER(vp)]
     L.rrh_gpu_tile.argtypes = [vp, vp, C.POINTER(rt_camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                C.c_uint64, vp, vp, C.POINTER(rt_stats)]
     _lib = L

@@ -79,10 +79,11 @@ def make_cfg(width, height, spp, max_depth=MAX_DEPTH, seed=0, window=None, tile_
 
 
 class GpuScene:
-    def __init__(self, ctx, scene):
+    def __init__(self, ctx, scene, device_build=False):
         self.ctx = ctx
         h = C.c_void_p()
-        _check(F.lib().rrh_scene_upload(ctx._h, scene.desc, C.byref(h)))
+        flags = F.RT_COMMIT_DEVICE_LBVH if device_build else F.RT_COMMIT_HOST_SAH
+        _check(F.lib().rrh_scene_upload_ex(ctx._h, scene.desc, flags, C.byref(h)))
         self._h = h
 
     def info(self):
@@ -107,8 +108,9 @@ class Context:
         self._h = h
         self.device = device
 
-    def upload(self, scene):
-        return GpuScene(self, scene)
+    def upload(self, scene, device_build=False):
+        """rt_scene_create + set_* + rt_scene_commit_ex; device_build=True builds the BVH on the GPU (row f3)."""
+        return GpuScene(self, scene, device_build)
 
     def render(self, gscene, camera, cfg):
         """rt_render: returns (rgb_sum[H,W,3] f64, n[H,W] u32, rt_stats)."""

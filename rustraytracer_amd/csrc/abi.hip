@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "bvh_build.h"
+#include "bvh_gpu.h"
 #include "device/kernels.hip"
 
 using namespace rtd;
@@ -339,44 +340,19 @@ static int validate_scene(const rt_scene* s) {
     return RT_OK;
 }
 
-int rt_scene_commit(rt_scene* s) {
+int rt_scene_commit(rt_scene* s) { return rt_scene_commit_ex(s, RT_COMMIT_HOST_SAH); }
+
+int rt_scene_commit_ex(rt_scene* s, uint32_t flags) {
     SCENE_MUTABLE(s);
+    if (flags & ~(uint32_t)RT_COMMIT_DEVICE_LBVH) return fail(RT_ERR_INVALID_ARG, "unknown commit flags 0x%x", flags);
     int rc = validate_scene(s);
     if (rc != RT_OK) return rc;
     HIP_TRY(hipSetDevice(s->ctx->device));
-    BvhOut bvh;
-    build_bvh(s->prims.data(), s->prims.size(), bvh);
-    if (bvh.depth + 1 > (uint32_t)kMaxBvhDepth) return fail(RT_ERR_UNSUPPORTED, "BVH depth %u exceeds the traversal stack", bvh.depth);
-    // leaf-ordered triangle vertices + ids
     const size_t np = s->prims.size();
-    std::vector<uint32_t> leaf_prim(np);
-    std::vector<double> leaf_tri(np * 9, 0.0);
-    uint64_t n_tri = 0;
-    for (size_t i = 0; i < np; i++) {
-        const uint32_t id = bvh.order[i];
-        const rt_primitive& p = s->prims[id];
-        if (p.kind == RT_PRIM_TRIANGLE) {
-            const auto& m = s->meshes[p.mesh_index];
-            for (int v = 0; v < 3; v++) {
-                const uint32_t vi = m.ind[p.tri_ind + v];
-                for (int a = 0; a < 3; a++) leaf_tri[i * 9 + v * 3 + a] = m.p[3 * vi + a];
-            }
-            leaf_prim[i] = id;
-            n_tri++;
-        } else {
-            // sphere / rect: parameters + {kind, transform index + 1} ride in the vertex slot (geom.h: leaf_step)
-            for (int a = 0; a < 5; a++) leaf_tri[i * 9 + a] = p.v[a];
-            const uint64_t meta = (uint64_t)(p.kind & 0xffu) | ((uint64_t)(uint32_t)(p.xform_index + 1) << 32);
-            std::memcpy(&leaf_tri[i * 9 + 5], &meta, 8);
-            leaf_prim[i] = id | kLeafOther;
-        }
-    }
     s->info = rt_scene_info{};
     DevScene& d = s->dev;
     d = DevScene{};
-    if ((rc = upload(s, bvh.nodes.data(), bvh.nodes.size(), &d.nodes)) != RT_OK) return rc;
-    if ((rc = upload(s, leaf_prim.data(), leaf_prim.size(), &d.leaf_prim)) != RT_OK) return rc;
-    if ((rc = upload(s, leaf_tri.data(), leaf_tri.size(), &d.leaf_tri)) != RT_OK) return rc;
+    // records the builders and the kernels read
     if ((rc = upload(s, s->prims.data(), s->prims.size(), &d.prims)) != RT_OK) return rc;
     std::vector<DevMesh> dm(s->meshes.size());
     uint32_t has_uv = 0;
@@ -393,15 +369,67 @@ int rt_scene_commit(rt_scene* s) {
     if ((rc = upload(s, s->mats.data(), s->mats.size(), &d.mats)) != RT_OK) return rc;
     if ((rc = upload(s, s->texs.data(), s->texs.size(), &d.texs)) != RT_OK) return rc;
     if ((rc = upload(s, s->lights.data(), s->lights.size(), &d.lights)) != RT_OK) return rc;
+    uint64_t n_tri = 0;
+    uint32_t depth = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (flags & RT_COMMIT_DEVICE_LBVH) {
+        // next-row f3: the tree is built where the primitives already are (bvh_gpu.hip)
+        DeviceBvh gb;
+        char berr[400] = "";
+        rc = build_bvh_device(s->ctx->stream, d.prims, d.meshes, (uint32_t)np, &gb, berr, sizeof(berr));
+        if (rc != RT_OK) return fail(rc, "%s", berr);
+        for (void* p : {(void*)gb.nodes, (void*)gb.leaf_prim, (void*)gb.leaf_tri})
+            if (p) s->allocs.push_back(p);
+        d.nodes = gb.nodes;
+        d.leaf_prim = gb.leaf_prim;
+        d.leaf_tri = gb.leaf_tri;
+        d.n_nodes = gb.n_nodes;
+        s->info.device_bytes_total += (uint64_t)gb.n_nodes * sizeof(DevNode) + np * (sizeof(uint32_t) + 9 * sizeof(double));
+        depth = gb.depth;
+        n_tri = gb.n_triangles;
+        s->info.build_device_ms = gb.build_ms;
+    } else {
+        BvhOut bvh;
+        build_bvh(s->prims.data(), s->prims.size(), bvh);
+        if (bvh.depth + 1 > (uint32_t)kMaxBvhDepth) return fail(RT_ERR_UNSUPPORTED, "BVH depth %u exceeds the traversal stack", bvh.depth);
+        // leaf-ordered triangle vertices + ids
+        std::vector<uint32_t> leaf_prim(np);
+        std::vector<double> leaf_tri(np * 9, 0.0);
+        for (size_t i = 0; i < np; i++) {
+            const uint32_t id = bvh.order[i];
+            const rt_primitive& p = s->prims[id];
+            if (p.kind == RT_PRIM_TRIANGLE) {
+                const auto& m = s->meshes[p.mesh_index];
+                for (int v = 0; v < 3; v++) {
+                    const uint32_t vi = m.ind[p.tri_ind + v];
+                    for (int a = 0; a < 3; a++) leaf_tri[i * 9 + v * 3 + a] = m.p[3 * vi + a];
+                }
+                leaf_prim[i] = id;
+                n_tri++;
+            } else {
+                // sphere / rect: parameters + {kind, transform index + 1} ride in the vertex slot (geom.h: leaf_step)
+                for (int a = 0; a < 5; a++) leaf_tri[i * 9 + a] = p.v[a];
+                const uint64_t meta = (uint64_t)(p.kind & 0xffu) | ((uint64_t)(uint32_t)(p.xform_index + 1) << 32);
+                std::memcpy(&leaf_tri[i * 9 + 5], &meta, 8);
+                leaf_prim[i] = id | kLeafOther;
+            }
+        }
+        if ((rc = upload(s, bvh.nodes.data(), bvh.nodes.size(), &d.nodes)) != RT_OK) return rc;
+        if ((rc = upload(s, leaf_prim.data(), leaf_prim.size(), &d.leaf_prim)) != RT_OK) return rc;
+        if ((rc = upload(s, leaf_tri.data(), leaf_tri.size(), &d.leaf_tri)) != RT_OK) return rc;
+        d.n_nodes = (uint32_t)bvh.nodes.size();
+        depth = bvh.depth;
+    }
+    s->info.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    s->info.build_flags = flags;
     d.n_prims = (uint32_t)np;
     d.n_lights = (uint32_t)s->lights.size();
-    d.n_nodes = (uint32_t)bvh.nodes.size();
     d.mesh_has_uv = has_uv;
     s->info.n_prims = np;
     s->info.n_triangles = n_tri;
     s->info.n_others = np - n_tri;
-    s->info.n_bvh_nodes = bvh.nodes.size();
-    s->info.bvh_depth = bvh.depth;
+    s->info.n_bvh_nodes = d.n_nodes;
+    s->info.bvh_depth = depth;
     s->info.node_bytes = sizeof(DevNode);
     s->info.tri_bytes = 9 * sizeof(double) + sizeof(uint32_t);
     s->info.other_bytes = 6 * sizeof(double) + sizeof(uint32_t);  // v[5] + meta in the leaf slot, + id

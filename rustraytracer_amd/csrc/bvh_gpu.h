@@ -1,0 +1,28 @@
+// bvh_gpu.h -- device BVH builder interface (see bvh_gpu.hip).  SURVEY.md section 8, row f3.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "device/scene_dev.h"
+
+namespace rtd {
+
+struct DeviceBvh {
+    DevNode* nodes = nullptr;      // n_nodes entries, node 0 = root (always internal), breadth-first order
+    uint32_t* leaf_prim = nullptr; // n entries: leaf order -> prim index | kLeafOther
+    double* leaf_tri = nullptr;    // n * 9 doubles: the leaf slots (geom.h: leaf_step)
+    uint32_t n_nodes = 0;
+    uint32_t depth = 0;            // depth of the 4-wide tree (root = 0)
+    uint64_t n_triangles = 0;
+    float build_ms = 0.0f;         // device time of the whole build (HIP events)
+};
+
+// Builds the traversal structure of `n` primitives that are already resident in HBM (`d_prims`, with the
+// caller-supplied f64 boxes of rt_primitive, and `d_meshes` for the triangle vertices).  The three result
+// arrays are hipMalloc'ed and owned by the caller.  Returns 0, or a negative rt_status with a message in `err`.
+int build_bvh_device(hipStream_t stream, const rt_primitive* d_prims, const DevMesh* d_meshes, uint32_t n,
+                     DeviceBvh* out, char* err, size_t err_len);
+
+}  // namespace rtd

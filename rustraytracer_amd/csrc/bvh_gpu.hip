@@ -1,0 +1,634 @@
+// bvh_gpu.hip -- BVH construction on the device.
+//
+// Replaces BvhNode::new (src/hittable.rs:637-752: recursive median split on a random axis with a sort at
+// every level and one entropy RNG per node) for callers that re-commit geometry often.  The reference's
+// traversal visits both children of every node it enters (hittable.rs:604-605), so its answer does not
+// depend on the tree; the device traversal keeps that property because a primitive is gated
+// only by the f64 slab test of its OWN box (geom.h: leaf_step).  Any topology therefore renders the same
+// film bit for bit, and the builder is free to be a linear BVH:
+//
+//   kb_bounds   centroid bounds of the scene (block reduction + ordered-integer atomics)
+//   kb_morton   63-bit Morton key of every centroid (21 bits per axis)
+//   kb_hist / kb_scan / kb_scatter   stable LSD radix sort, 8 passes x 8 bits, 2048-key tiles; ranks inside a
+//               wave come from eight __ballot()s per key (64-wide match), so a tile needs no LDS atomics
+//   kb_tree     binary radix tree over the sorted keys (Karras 2012; duplicates split by index)
+//   kb_refit    leaf-to-root f64 boxes, "all triangles" flags; second arrival at a node does the union
+//   kb_emit     one launch per level of the 4-wide tree: a node adopts the grandchildren of larger surface
+//               area until it has four children, subtrees of <= 4 triangles become one leaf, spheres and
+//               rects stay alone in theirs; child boxes are rounded OUTWARD to f32 (scene_dev.h: DevNode)
+//   kb_leaves   leaf slots: vertices (or sphere / rect parameters) gathered in sorted order
+//
+// Everything runs on one stream; the host only reads back the per-level queue length.
+#include "bvh_gpu.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+namespace rtd {
+
+namespace {
+
+typedef unsigned long long ull;
+
+constexpr int kSortThreads = 256;
+constexpr int kSortItems = 8;
+constexpr int kSortTile = kSortThreads * kSortItems;
+
+struct BuildGlobals {
+    ull cmin[3], cmax[3];  // centroid bounds, order-preserving integer encoding of f64
+    uint32_t node_count;   // 4-wide nodes allocated so far
+    uint32_t q_count[2];   // work items of the current / next level
+    uint32_t unsorted;     // sort self-check: adjacent pairs out of order
+    uint32_t n_tri;
+    uint32_t overflow;     // node pool exhausted (cannot happen: one 4-wide node per binary node at most)
+};
+
+__device__ inline ull enc_f64(double d) {
+    const ull b = (ull)__double_as_longlong(d);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ inline double dec_f64(ull e) {
+    const ull b = (e >> 63) ? (e & 0x7fffffffffffffffull) : ~e;
+    return __longlong_as_double((long long)b);
+}
+
+__device__ inline float f_down(double x) {  // largest float <= x
+    float f = (float)x;
+    if ((double)f > x) {
+        const uint32_t u = __float_as_uint(f);
+        f = f > 0.0f ? __uint_as_float(u - 1u) : (f < 0.0f ? __uint_as_float(u + 1u) : __uint_as_float(0x80000001u));
+    }
+    return f;
+}
+__device__ inline float f_up(double x) {  // smallest float >= x
+    float f = (float)x;
+    if ((double)f < x) {
+        const uint32_t u = __float_as_uint(f);
+        f = f > 0.0f ? __uint_as_float(u + 1u) : (f < 0.0f ? __uint_as_float(u - 1u) : __uint_as_float(0x00000001u));
+    }
+    return f;
+}
+
+__global__ void kb_init(BuildGlobals* g) {
+    for (int a = 0; a < 3; a++) {
+        g->cmin[a] = ~0ull;
+        g->cmax[a] = 0ull;
+    }
+    g->node_count = 1;  // the root
+    g->q_count[0] = 1;
+    g->q_count[1] = 0;
+    g->unsorted = 0;
+    g->n_tri = 0;
+    g->overflow = 0;
+}
+
+__device__ inline double wave_min(double v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_down(v, o, 64));
+    return v;
+}
+__device__ inline double wave_max(double v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void kb_bounds(const rt_primitive* __restrict__ prims, uint32_t n, BuildGlobals* g) {
+    double mn[3] = {1e308, 1e308, 1e308}, mx[3] = {-1e308, -1e308, -1e308};
+    uint32_t tris = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const rt_primitive& p = prims[i];
+        for (int a = 0; a < 3; a++) {
+            const double c = (p.bbox_min[a] + p.bbox_max[a]) * 0.5;
+            mn[a] = fmin(mn[a], c);
+            mx[a] = fmax(mx[a], c);
+        }
+        tris += p.kind == RT_PRIM_TRIANGLE;
+    }
+    __shared__ double s_mn[4][3], s_mx[4][3];
+    __shared__ uint32_t s_tris[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int a = 0; a < 3; a++) {
+        const double lo = wave_min(mn[a]), hi = wave_max(mx[a]);
+        if (lane == 0) {
+            s_mn[wave][a] = lo;
+            s_mx[wave][a] = hi;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) tris += __shfl_down(tris, o, 64);
+    if (lane == 0) s_tris[wave] = tris;
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        const double lo = fmin(fmin(s_mn[0][a], s_mn[1][a]), fmin(s_mn[2][a], s_mn[3][a]));
+        const double hi = fmax(fmax(s_mx[0][a], s_mx[1][a]), fmax(s_mx[2][a], s_mx[3][a]));
+        atomicMin(&g->cmin[a], enc_f64(lo));
+        atomicMax(&g->cmax[a], enc_f64(hi));
+    }
+    if (threadIdx.x == 3) atomicAdd(&g->n_tri, s_tris[0] + s_tris[1] + s_tris[2] + s_tris[3]);
+}
+
+__device__ inline ull spread21(ull x) {  // bit i -> bit 3i
+    x &= 0x1fffffull;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void kb_morton(const rt_primitive* __restrict__ prims, uint32_t n,
+                                                 const BuildGlobals* g, ull* keys, uint32_t* vals) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const rt_primitive& p = prims[i];
+    ull q[3];
+    for (int a = 0; a < 3; a++) {
+        const double lo = dec_f64(g->cmin[a]), hi = dec_f64(g->cmax[a]);
+        const double c = (p.bbox_min[a] + p.bbox_max[a]) * 0.5;
+        const double ext = hi - lo;
+        double f = ext > 0.0 ? (c - lo) / ext * 2097152.0 : 0.0;
+        f = fmin(fmax(f, 0.0), 2097151.0);
+        q[a] = (ull)f;
+    }
+    keys[i] = spread21(q[0]) | (spread21(q[1]) << 1) | (spread21(q[2]) << 2);
+    vals[i] = i;
+}
+
+// ---- radix sort: histogram of one 8-bit digit per tile, laid out [digit][tile]
+__global__ __launch_bounds__(kSortThreads) void kb_hist(const ull* __restrict__ keys, uint32_t n, int shift,
+                                                        uint32_t* hist, uint32_t n_tiles) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kSortTile;
+#pragma unroll
+    for (int r = 0; r < kSortItems; r++) {
+        const uint32_t i = base + r * kSortThreads + threadIdx.x;
+        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * n_tiles + blockIdx.x] = h[threadIdx.x];
+}
+
+// exclusive prefix sum of m counters in place, one block
+__global__ __launch_bounds__(1024) void kb_scan(uint32_t* a, uint32_t m) {
+    __shared__ uint32_t part[1024];
+    const uint32_t chunk = (m + 1023u) / 1024u;
+    const uint32_t b = threadIdx.x * chunk, e = b + chunk < m ? b + chunk : m;
+    uint32_t s = 0;
+    for (uint32_t i = b; i < e; i++) s += a[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024u; o <<= 1) {
+        const uint32_t v = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - s;  // exclusive
+    for (uint32_t i = b; i < e; i++) {
+        const uint32_t v = a[i];
+        a[i] = run;
+        run += v;
+    }
+}
+
+// stable scatter of one tile: wave w owns keys [w*512, (w+1)*512) of the tile, 8 rounds of 64
+__global__ __launch_bounds__(kSortThreads) void kb_scatter(const ull* __restrict__ keys_in,
+                                                           const uint32_t* __restrict__ vals_in, ull* keys_out,
+                                                           uint32_t* vals_out, uint32_t n, int shift,
+                                                           const uint32_t* __restrict__ hist, uint32_t n_tiles) {
+    __shared__ uint32_t cnt[4][256];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (int w = 0; w < 4; w++) cnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kSortTile + wave * (64u * kSortItems);
+    const ull below = (1ull << lane) - 1ull;
+    ull k[kSortItems];
+    uint32_t v[kSortItems], lr[kSortItems];
+#pragma unroll
+    for (int r = 0; r < kSortItems; r++) {
+        const uint32_t i = base + r * 64u + lane;
+        const bool valid = i < n;
+        k[r] = valid ? keys_in[i] : ~0ull;
+        v[r] = valid ? vals_in[i] : 0u;
+        const uint32_t digit = (uint32_t)(k[r] >> shift) & 255u;
+        ull m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (digit >> b) & 1u;
+            const ull bal = __ballot(bit);
+            m &= bit ? bal : ~bal;
+        }
+        const uint32_t rank = (uint32_t)__popcll(m & below);
+        const uint32_t old = cnt[wave][digit];  // every lane reads before the group's first lane adds
+        if (valid && rank == 0) cnt[wave][digit] = old + (uint32_t)__popcll(m);
+        lr[r] = old + rank;
+    }
+    __syncthreads();
+    {   // digit d: global base of this tile, then the waves of the tile in order
+        const uint32_t d = threadIdx.x;
+        uint32_t gbase = hist[d * n_tiles + blockIdx.x];
+        for (int w = 0; w < 4; w++) {
+            const uint32_t c = cnt[w][d];
+            cnt[w][d] = gbase;
+            gbase += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSortItems; r++) {
+        const uint32_t i = base + r * 64u + lane;
+        if (i < n) {
+            const uint32_t digit = (uint32_t)(k[r] >> shift) & 255u;
+            const uint32_t dst = cnt[wave][digit] + lr[r];
+            keys_out[dst] = k[r];
+            vals_out[dst] = v[r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void kb_check_sorted(const ull* __restrict__ keys, uint32_t n, BuildGlobals* g) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i + 1 < n && keys[i] > keys[i + 1]) atomicAdd(&g->unsorted, 1u);
+}
+
+// ---- binary radix tree (Karras 2012).  Internal nodes 0..n-2, node 0 = root; a child c >= 0 is an
+// internal node, c < 0 is leaf ~c (position in sorted order).
+struct Tree {
+    int32_t* left;       // [n-1]
+    int32_t* right;      // [n-1]
+    int32_t* parent;     // [n-1] parent of an internal node (-1 for the root)
+    int32_t* leaf_par;   // [n]
+    uint32_t* first;     // [n-1] range of sorted positions covered
+    uint32_t* last;      // [n-1]
+    double* box;         // [n-1][6] min xyz, max xyz
+    uint32_t* flag;      // [n-1] arrivals (refit)
+    uint32_t* all_tri;   // [n-1] subtree holds triangles only
+};
+
+__device__ inline int key_delta(const ull* __restrict__ keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    const ull a = keys[i], b = keys[j];
+    if (a == b) return 64 + __clz((uint32_t)(i ^ j));
+    return __clzll((long long)(a ^ b));
+}
+
+__global__ __launch_bounds__(256) void kb_tree(const ull* __restrict__ keys, int n, Tree t) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = key_delta(keys, n, i, i + 1) - key_delta(keys, n, i, i - 1) >= 0 ? 1 : -1;
+    const int dmin = key_delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (key_delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int s = lmax / 2; s >= 1; s /= 2)
+        if (key_delta(keys, n, i, i + (l + s) * d) > dmin) l += s;
+    const int j = i + l * d;
+    const int dnode = key_delta(keys, n, i, j);
+    int s = 0;
+    for (int step = l;;) {
+        step = (step + 1) / 2;
+        if (key_delta(keys, n, i, i + (s + step) * d) > dnode) s += step;
+        if (step <= 1) break;
+    }
+    const int gamma = i + s * d + (d < 0 ? -1 : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    const int32_t lc = lo == gamma ? ~gamma : gamma;
+    const int32_t rc = hi == gamma + 1 ? ~(gamma + 1) : gamma + 1;
+    t.left[i] = lc;
+    t.right[i] = rc;
+    t.first[i] = (uint32_t)lo;
+    t.last[i] = (uint32_t)hi;
+    if (lc >= 0) t.parent[lc] = i; else t.leaf_par[~lc] = i;
+    if (rc >= 0) t.parent[rc] = i; else t.leaf_par[~rc] = i;
+    if (i == 0) t.parent[0] = -1;
+}
+
+__device__ inline double ld_coherent(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const ull*>(p), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ inline uint32_t ld_coherent(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ inline void child_box(const Tree& t, const rt_primitive* __restrict__ prims,
+                                 const uint32_t* __restrict__ order, int32_t c, double* b, bool& tri) {
+    if (c >= 0) {
+        for (int a = 0; a < 6; a++) b[a] = ld_coherent(&t.box[(size_t)c * 6 + a]);
+        tri = ld_coherent(&t.all_tri[c]) != 0;
+    } else {
+        const rt_primitive& p = prims[order[~c]];
+        for (int a = 0; a < 3; a++) {
+            b[a] = p.bbox_min[a];
+            b[3 + a] = p.bbox_max[a];
+        }
+        tri = p.kind == RT_PRIM_TRIANGLE;
+    }
+}
+
+__global__ __launch_bounds__(256) void kb_refit(const rt_primitive* __restrict__ prims,
+                                                const uint32_t* __restrict__ order, int n, Tree t) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    int p = t.leaf_par[j];
+    while (p >= 0) {
+        __threadfence();
+        if (atomicAdd(&t.flag[p], 1u) == 0u) return;  // the sibling subtree is not finished: its thread goes on
+        __threadfence();
+        double bl[6], br[6];
+        bool tl, tr;
+        child_box(t, prims, order, t.left[p], bl, tl);
+        child_box(t, prims, order, t.right[p], br, tr);
+        for (int a = 0; a < 3; a++) {
+            t.box[(size_t)p * 6 + a] = fmin(bl[a], br[a]);
+            t.box[(size_t)p * 6 + 3 + a] = fmax(bl[3 + a], br[3 + a]);
+        }
+        t.all_tri[p] = (tl && tr) ? 1u : 0u;
+        p = t.parent[p];
+    }
+}
+
+// ---- 4-wide emission, one level per launch.  Work item = (binary node) | (4-wide node index << 32).
+__device__ inline bool leafable(const Tree& t, int32_t c) {
+    return t.all_tri[c] != 0u && t.last[c] - t.first[c] + 1u <= (uint32_t)kMaxLeafPrims;
+}
+__device__ inline double box_area(const double* b) {
+    const double dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+__global__ __launch_bounds__(256) void kb_emit(const rt_primitive* __restrict__ prims,
+                                               const uint32_t* __restrict__ order, Tree t, const ull* q_in, ull* q_out,
+                                               BuildGlobals* g, int cur, DevNode* nodes, uint32_t max_nodes) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g->q_count[cur]) return;
+    const ull item = q_in[i];
+    const int32_t b = (int32_t)(uint32_t)(item & 0xffffffffull);
+    const uint32_t out = (uint32_t)(item >> 32);
+    int32_t cand[4];
+    int nc;
+    if (leafable(t, b)) {  // only the root can arrive here: the whole scene is one leaf, wrapped in node 0
+        cand[0] = b;
+        nc = 1;
+    } else {
+        cand[0] = t.left[b];
+        cand[1] = t.right[b];
+        nc = 2;
+        while (nc < 4) {
+            int best = -1;
+            double best_a = -1.0;
+            for (int k = 0; k < nc; k++) {
+                const int32_t c = cand[k];
+                if (c >= 0 && !leafable(t, c)) {
+                    const double a = box_area(&t.box[(size_t)c * 6]);
+                    if (a > best_a) {
+                        best_a = a;
+                        best = k;
+                    }
+                }
+            }
+            if (best < 0) break;
+            const int32_t c = cand[best];
+            cand[best] = t.left[c];
+            cand[nc++] = t.right[c];
+        }
+    }
+    DevNode nd;
+    for (int k = 0; k < 4; k++) {
+        nd.pad[k] = 0;
+        if (k >= nc) {
+            nd.child[k] = kNoChild;
+            nd.lo_x[k] = nd.lo_y[k] = nd.lo_z[k] = 0.0f;
+            nd.hi_x[k] = nd.hi_y[k] = nd.hi_z[k] = 0.0f;
+            continue;
+        }
+        const int32_t c = cand[k];
+        double bx[6];
+        if (c >= 0) {
+            for (int a = 0; a < 6; a++) bx[a] = t.box[(size_t)c * 6 + a];
+        } else {
+            const rt_primitive& p = prims[order[~c]];
+            for (int a = 0; a < 3; a++) {
+                bx[a] = p.bbox_min[a];
+                bx[3 + a] = p.bbox_max[a];
+            }
+        }
+        nd.lo_x[k] = f_down(bx[0]); nd.lo_y[k] = f_down(bx[1]); nd.lo_z[k] = f_down(bx[2]);
+        nd.hi_x[k] = f_up(bx[3]);   nd.hi_y[k] = f_up(bx[4]);   nd.hi_z[k] = f_up(bx[5]);
+        if (c < 0) {
+            const uint32_t j = (uint32_t)~c;
+            const bool other = prims[order[j]].kind != RT_PRIM_TRIANGLE;
+            nd.child[k] = -1 - (int32_t)((j * 8u) | (other ? kLeafCodeOther : 0u));
+        } else if (leafable(t, c)) {
+            const uint32_t first = t.first[c], count = t.last[c] - first + 1u;
+            nd.child[k] = -1 - (int32_t)(first * 8u + (count - 1u));
+        } else {
+            const uint32_t idx = atomicAdd(&g->node_count, 1u);
+            if (idx >= max_nodes) {
+                g->overflow = 1;
+                nd.child[k] = kNoChild;
+                continue;
+            }
+            nd.child[k] = (int32_t)idx;
+            const uint32_t slot = atomicAdd(&g->q_count[cur ^ 1], 1u);
+            q_out[slot] = (ull)(uint32_t)c | ((ull)idx << 32);
+        }
+    }
+    nodes[out] = nd;
+}
+
+__global__ void kb_next_level(BuildGlobals* g, int cur) { g->q_count[cur] = 0; }
+
+// the scene is a single primitive: node 0 wraps its leaf
+__global__ void kb_single(const rt_primitive* __restrict__ prims, DevNode* nodes) {
+    const rt_primitive& p = prims[0];
+    DevNode nd;
+    for (int k = 0; k < 4; k++) {
+        nd.pad[k] = 0;
+        nd.child[k] = kNoChild;
+        nd.lo_x[k] = nd.lo_y[k] = nd.lo_z[k] = 0.0f;
+        nd.hi_x[k] = nd.hi_y[k] = nd.hi_z[k] = 0.0f;
+    }
+    nd.lo_x[0] = f_down(p.bbox_min[0]); nd.lo_y[0] = f_down(p.bbox_min[1]); nd.lo_z[0] = f_down(p.bbox_min[2]);
+    nd.hi_x[0] = f_up(p.bbox_max[0]);   nd.hi_y[0] = f_up(p.bbox_max[1]);   nd.hi_z[0] = f_up(p.bbox_max[2]);
+    nd.child[0] = -1 - (int32_t)(p.kind != RT_PRIM_TRIANGLE ? kLeafCodeOther : 0u);
+    nodes[0] = nd;
+}
+
+// leaf slots in sorted order (same contents as rt_scene_commit's host loop, abi.hip)
+__global__ __launch_bounds__(256) void kb_leaves(const rt_primitive* __restrict__ prims,
+                                                 const DevMesh* __restrict__ meshes,
+                                                 const uint32_t* __restrict__ order, uint32_t n, uint32_t* leaf_prim,
+                                                 double* leaf_tri) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t id = order[i];
+    const rt_primitive& p = prims[id];
+    double* o = leaf_tri + (size_t)i * 9;
+    if (p.kind == RT_PRIM_TRIANGLE) {
+        const DevMesh& m = meshes[p.mesh_index];
+        for (int v = 0; v < 3; v++) {
+            const uint32_t vi = m.ind[p.tri_ind + v];
+            for (int a = 0; a < 3; a++) o[v * 3 + a] = m.p[3 * (size_t)vi + a];
+        }
+        leaf_prim[i] = id;
+    } else {
+        for (int a = 0; a < 5; a++) o[a] = p.v[a];
+        const ull meta = (ull)(p.kind & 0xffu) | ((ull)(uint32_t)(p.xform_index + 1) << 32);
+        o[5] = __longlong_as_double((long long)meta);
+        o[6] = o[7] = o[8] = 0.0;
+        leaf_prim[i] = id | kLeafOther;
+    }
+}
+
+struct Scratch {
+    std::vector<void*> ptrs;
+    ~Scratch() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+    template <typename T>
+    hipError_t get(T** out, size_t count) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, (count ? count : 1) * sizeof(T));
+        if (e == hipSuccess) ptrs.push_back(p);
+        *out = (T*)p;
+        return e;
+    }
+};
+
+int bfail(char* err, size_t n, int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    if (err && n) vsnprintf(err, n, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+}  // namespace
+
+#define B_TRY(expr)                                                                                          \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return bfail(err, err_len, e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP, "%s failed: %s (%s:%d)", \
+                         #expr, hipGetErrorString(e_), __FILE__, __LINE__);                                  \
+    } while (0)
+
+int build_bvh_device(hipStream_t stream, const rt_primitive* d_prims, const DevMesh* d_meshes, uint32_t n,
+                     DeviceBvh* out, char* err, size_t err_len) {
+    *out = DeviceBvh{};
+    if (n == 0) return RT_OK;
+    if (n >= (1u << 27)) return bfail(err, err_len, RT_ERR_UNSUPPORTED, "more than 2^27 primitives");
+    Scratch tmp;   // freed on every exit
+    Scratch keep;  // results: released to the caller on success
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    B_TRY(hipEventCreate(&ev0));
+    B_TRY(hipEventCreate(&ev1));
+    struct EvGuard {
+        hipEvent_t a, b;
+        ~EvGuard() {
+            (void)hipEventDestroy(a);
+            (void)hipEventDestroy(b);
+        }
+    } evg{ev0, ev1};
+    B_TRY(hipEventRecord(ev0, stream));
+
+    BuildGlobals* g;
+    ull *keys[2], *queue[2];
+    uint32_t *vals[2], *hist;
+    const uint32_t n_tiles = (n + kSortTile - 1) / kSortTile;
+    const uint32_t nb = (n + 255u) / 256u;
+    B_TRY(tmp.get(&g, 1));
+    B_TRY(tmp.get(&keys[0], n));
+    B_TRY(tmp.get(&keys[1], n));
+    B_TRY(tmp.get(&vals[0], n));
+    B_TRY(tmp.get(&vals[1], n));
+    B_TRY(tmp.get(&hist, 256 * (size_t)n_tiles));
+    hipLaunchKernelGGL(kb_init, dim3(1), dim3(1), 0, stream, g);
+    hipLaunchKernelGGL(kb_bounds, dim3(std::min<uint32_t>(nb, 1024u)), dim3(256), 0, stream, d_prims, n, g);
+    hipLaunchKernelGGL(kb_morton, dim3(nb), dim3(256), 0, stream, d_prims, n, g, keys[0], vals[0]);
+    int cur = 0;
+    for (int shift = 0; shift < 64; shift += 8) {
+        hipLaunchKernelGGL(kb_hist, dim3(n_tiles), dim3(kSortThreads), 0, stream, keys[cur], n, shift, hist, n_tiles);
+        hipLaunchKernelGGL(kb_scan, dim3(1), dim3(1024), 0, stream, hist, 256u * n_tiles);
+        hipLaunchKernelGGL(kb_scatter, dim3(n_tiles), dim3(kSortThreads), 0, stream, keys[cur], vals[cur],
+                           keys[cur ^ 1], vals[cur ^ 1], n, shift, hist, n_tiles);
+        cur ^= 1;
+    }
+    const ull* skeys = keys[cur];
+    const uint32_t* order = vals[cur];
+    hipLaunchKernelGGL(kb_check_sorted, dim3(nb), dim3(256), 0, stream, skeys, n, g);
+
+    DeviceBvh r;
+    B_TRY(keep.get(&r.leaf_prim, n));
+    B_TRY(keep.get(&r.leaf_tri, (size_t)n * 9));
+    hipLaunchKernelGGL(kb_leaves, dim3(nb), dim3(256), 0, stream, d_prims, d_meshes, order, n, r.leaf_prim, r.leaf_tri);
+
+    DevNode* pool = nullptr;  // one 4-wide node per binary internal node at most
+    const uint32_t max_nodes = n > 1 ? n - 1 : 1;
+    B_TRY(tmp.get(&pool, max_nodes));
+    uint32_t levels = 1;
+    BuildGlobals hg;
+    if (n == 1) {
+        hipLaunchKernelGGL(kb_single, dim3(1), dim3(1), 0, stream, d_prims, pool);
+        B_TRY(hipMemcpyAsync(&hg, g, sizeof(hg), hipMemcpyDeviceToHost, stream));
+        B_TRY(hipStreamSynchronize(stream));
+        hg.node_count = 1;
+    } else {
+        Tree t;
+        const size_t ni = n - 1;
+        B_TRY(tmp.get(&t.left, ni));
+        B_TRY(tmp.get(&t.right, ni));
+        B_TRY(tmp.get(&t.parent, ni));
+        B_TRY(tmp.get(&t.leaf_par, n));
+        B_TRY(tmp.get(&t.first, ni));
+        B_TRY(tmp.get(&t.last, ni));
+        B_TRY(tmp.get(&t.box, ni * 6));
+        B_TRY(tmp.get(&t.flag, ni));
+        B_TRY(tmp.get(&t.all_tri, ni));
+        B_TRY(tmp.get(&queue[0], ni));
+        B_TRY(tmp.get(&queue[1], ni));
+        B_TRY(hipMemsetAsync(t.flag, 0, ni * sizeof(uint32_t), stream));
+        B_TRY(hipMemsetAsync(queue[0], 0, sizeof(ull), stream));  // first item: binary root 0 -> node 0
+        hipLaunchKernelGGL(kb_tree, dim3(nb), dim3(256), 0, stream, skeys, (int)n, t);
+        hipLaunchKernelGGL(kb_refit, dim3(nb), dim3(256), 0, stream, d_prims, order, (int)n, t);
+        int q = 0;
+        uint32_t count = 1;
+        levels = 0;
+        while (count > 0) {
+            if (levels >= (uint32_t)kMaxBvhDepth)
+                return bfail(err, err_len, RT_ERR_UNSUPPORTED,
+                             "device-built BVH is deeper than the traversal stack allows (%d levels): commit with the host builder",
+                             kMaxBvhDepth);
+            hipLaunchKernelGGL(kb_emit, dim3((count + 255u) / 256u), dim3(256), 0, stream, d_prims, order, t, queue[q],
+                               queue[q ^ 1], g, q, pool, max_nodes);
+            hipLaunchKernelGGL(kb_next_level, dim3(1), dim3(1), 0, stream, g, q);
+            B_TRY(hipMemcpyAsync(&hg, g, sizeof(hg), hipMemcpyDeviceToHost, stream));
+            B_TRY(hipStreamSynchronize(stream));
+            count = hg.q_count[q ^ 1];
+            q ^= 1;
+            levels++;
+        }
+    }
+    B_TRY(hipGetLastError());
+    if (hg.unsorted) return bfail(err, err_len, RT_ERR_HIP, "device radix sort self-check failed (%u inversions)", hg.unsorted);
+    if (hg.overflow) return bfail(err, err_len, RT_ERR_HIP, "device BVH node pool overflow");
+    r.n_nodes = hg.node_count;
+    r.depth = levels > 0 ? levels - 1 : 0;
+    r.n_triangles = hg.n_tri;
+    // the pool was sized for the worst case: keep an exact copy
+    B_TRY(keep.get(&r.nodes, r.n_nodes));
+    B_TRY(hipMemcpyAsync(r.nodes, pool, (size_t)r.n_nodes * sizeof(DevNode), hipMemcpyDeviceToDevice, stream));
+    B_TRY(hipEventRecord(ev1, stream));
+    B_TRY(hipStreamSynchronize(stream));
+    B_TRY(hipEventElapsedTime(&r.build_ms, ev0, ev1));
+    keep.ptrs.clear();  // ownership passes to the caller
+    *out = r;
+    return RT_OK;
+}
+
+}  // namespace rtd

@@ -63,6 +63,10 @@ int rrh_camera_new(const double* from, const double* to, const double* up, doubl
 
 // Commit a flattened scene into a GPU scene handle through the C ABI.
 int rrh_scene_upload(rt_context* ctx, const rt_scene_desc* d, rt_scene** out) {
+    return rrh_scene_upload_ex(ctx, d, RT_COMMIT_HOST_SAH, out);
+}
+
+int rrh_scene_upload_ex(rt_context* ctx, const rt_scene_desc* d, uint32_t commit_flags, rt_scene** out) {
     if (!ctx || !d || !out) return RT_ERR_INVALID_ARG;
     rt_scene* s = nullptr;
     int rc = rt_scene_create(ctx, &s);
@@ -72,7 +76,7 @@ int rrh_scene_upload(rt_context* ctx, const rt_scene_desc* d, rt_scene** out) {
         (rc = rt_scene_set_transforms(s, d->xforms, d->n_xforms)) != RT_OK ||
         (rc = rt_scene_set_materials(s, d->materials, d->n_materials)) != RT_OK ||
         (rc = rt_scene_set_textures(s, d->textures, d->n_textures)) != RT_OK ||
-        (rc = rt_scene_set_lights(s, d->lights, d->n_lights)) != RT_OK || (rc = rt_scene_commit(s)) != RT_OK) {
+        (rc = rt_scene_set_lights(s, d->lights, d->n_lights)) != RT_OK || (rc = rt_scene_commit_ex(s, commit_flags)) != RT_OK) {
         rt_scene_destroy(s);
         return rc;
     }

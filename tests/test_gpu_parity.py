@@ -307,3 +307,71 @@ def test_full_size_scenes_bit_identical(gpu_ctx, case):
     assert rmse(np.where(finite, rg, 0), ng, np.where(finite, ro, 0), no) < RMSE_TOL
     assert np.array_equal(rg[finite], ro[finite])
     gs.close()
+
+
+# ------------------------------------------------------------------ next-row f3: BVH built on the GPU
+def _same_hits(gpu_ctx, sc, lo, hi, n_rays=100000, seed=7):
+    """device-built BVH == host-built BVH == oracle, prim index and t bit for bit"""
+    osc = O.OracleScene(sc)
+    g_host = gpu_ctx.upload(sc)
+    g_dev = gpu_ctx.upload(sc, device_build=True)
+    inf = g_dev.info()
+    assert inf["build_flags"] == F.RT_COMMIT_DEVICE_LBVH and inf["n_bvh_nodes"] >= 1 and inf["bvh_depth"] < 24
+    assert inf["n_prims"] == g_host.info()["n_prims"] and inf["n_triangles"] == g_host.info()["n_triangles"]
+    rng = np.random.default_rng(seed)
+    o, d = random_rays(rng, n_rays, lo, hi)
+    d[:500, 0] = 0.0
+    for tmin in (F.RT_SMALL, 0.0):
+        td, pd = gpu_ctx.intersect_batch(g_dev, o, d, tmin)
+        th, ph = gpu_ctx.intersect_batch(g_host, o, d, tmin)
+        to, po = osc.intersect_batch(o, d, tmin)
+        assert np.array_equal(pd, ph) and np.array_equal(td, th)
+        assert np.array_equal(pd, po) and np.array_equal(td, to)
+    g_host.close()
+    g_dev.close()
+    return inf
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_device_built_bvh_intersections(gpu_ctx, name):
+    make, lo, hi = SCENES[name]
+    inf = _same_hits(gpu_ctx, make(), lo, hi)
+    assert inf["build_device_ms"] > 0.0
+
+
+def test_device_built_bvh_edge_cases(gpu_ctx):
+    from tests.soup import SoupScene
+    rng = np.random.default_rng(3)
+    tri = np.array([[[0.0, 0.0, 0.0], [1.0, 0.0, 0.1], [0.0, 1.0, 0.2]]])
+    # 1 primitive; 3 triangles (root is one leaf); 5 (first split); a lone sphere; triangles + spheres
+    _same_hits(gpu_ctx, SoupScene(tri), -1.0, 2.0, 20000)
+    _same_hits(gpu_ctx, SoupScene(tri + rng.uniform(-1, 1, size=(3, 1, 3))), -2.0, 3.0, 20000)
+    _same_hits(gpu_ctx, SoupScene(tri + rng.uniform(-1, 1, size=(5, 1, 3))), -2.0, 3.0, 20000)
+    _same_hits(gpu_ctx, SoupScene(np.zeros((0, 3, 3)), spheres=[[0.5, 0.5, 0.5, 0.7]]), -2.0, 3.0, 20000)
+    _same_hits(gpu_ctx, SoupScene(tri + rng.uniform(-3, 3, size=(40, 1, 3)),
+                                  spheres=rng.uniform(0.2, 1.0, size=(7, 4))), -4.0, 5.0, 50000)
+    # 3000 copies of the same triangle and 3000 more sharing one centroid: equal Morton keys are split by index
+    same = np.repeat(tri, 3000, axis=0)
+    scaled = (tri - tri.mean(axis=1, keepdims=True)) * rng.uniform(0.5, 2.0, size=(3000, 1, 1)) + 2.0
+    inf = _same_hits(gpu_ctx, SoupScene(np.concatenate([same, scaled])), -1.0, 4.0, 50000)
+    assert inf["n_prims"] == 6000
+    # a non-multiple of the sort tile, random soup
+    soup = rng.uniform(-5, 5, size=(70001, 1, 3)) + rng.normal(scale=0.05, size=(70001, 3, 3))
+    _same_hits(gpu_ctx, SoupScene(soup), -6.0, 6.0, 100000)
+
+
+def test_device_built_bvh_renders_the_same_film(gpu_ctx):
+    """The film does not depend on the builder (a primitive is gated by the f64 test of its own box)."""
+    for make, W, H, spp in ((lambda: rr.cornell_box_statue(mesh_faces=30000, variant=0), 64, 64, 8),
+                            (lambda: rr.two_dragons(1920 / 1080, mesh_faces=20000, variant=0), 64, 36, 8)):
+        sc = make()
+        cfg = rr.make_cfg(W, H, spp, seed=5)
+        g_host, g_dev = gpu_ctx.upload(sc), gpu_ctx.upload(sc, device_build=True)
+        rh, nh, sh = gpu_ctx.render(g_host, sc.camera, cfg)
+        rd, nd, sd = gpu_ctx.render(g_dev, sc.camera, cfg)
+        assert np.array_equal(rh, rd) and np.array_equal(nh, nd)
+        assert (sh.rays_extension, sh.rays_shadow, sh.rays_probe) == (sd.rays_extension, sd.rays_shadow, sd.rays_probe)
+        ro, no, so = O.OracleScene(sc).render(sc.camera, cfg)
+        assert np.array_equal(rd, ro) and rmse(rd, nd, ro, no) < RMSE_TOL
+        g_host.close()
+        g_dev.close()

@@ -1,0 +1,37 @@
+"""Row f3: BVH build time and traversal quality, host binned SAH vs device LBVH (run on the GPU box)."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import rustraytracer_amd as rr
+
+CASES = [("c2", lambda: rr.cornell_box_statue(mesh_faces=400000, variant=0), 512, 512, 64),
+         ("c3", lambda: rr.plastic_dragon(mesh_faces=871414, variant=1), 1024, 1024, 16),
+         ("c4", lambda: rr.two_dragons(1920 / 1080, mesh_faces=871414, variant=0), 1920, 1080, 8)]
+ctx = rr.Context(0)
+out = []
+for name, make, W, H, spp in CASES:
+    sc = make()
+    row = {"scene": name}
+    for label, dev in (("host_sah", False), ("device_lbvh", True)):
+        t0 = time.time()
+        gs = ctx.upload(sc, device_build=dev)
+        wall = (time.time() - t0) * 1e3
+        inf = gs.info()
+        cfg = rr.make_cfg(W, H, spp)
+        ctx.render(gs, sc.camera, cfg)  # warm
+        t0 = time.time()
+        _, _, st = ctx.render(gs, sc.camera, cfg)
+        dt = time.time() - t0
+        _, _, stc = ctx.render(gs, sc.camera, rr.make_cfg(W, H, spp, count_traversal=True))
+        row[label] = {"upload_wall_ms": wall, "build_ms": inf["build_ms"], "build_device_ms": inf["build_device_ms"],
+                      "n_prims": inf["n_prims"], "nodes": inf["n_bvh_nodes"], "depth": inf["bvh_depth"],
+                      "Mrays_s": st.rays / dt / 1e6, "trace_ms": st.trace_ms, "kernel_ms": st.kernel_ms,
+                      "nodes_per_ray": stc.nodes_fetched / stc.rays, "tris_per_ray": stc.tris_tested / stc.rays}
+        gs.close()
+    out.append(row)
+    print(json.dumps(row), flush=True)
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/build_bench.json", "w"), indent=1)
