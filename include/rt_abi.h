@@ -199,9 +199,18 @@ typedef struct rt_render_cfg {
     uint32_t precision;       /* rt_precision                                  */
     uint32_t paths_in_flight; /* 0 = library default                           */
     uint32_t flags;           /* RT_RENDER_* below                             */
+    /* Progressive passes (next-row f4; render.rs:161-324 refines the picture while
+     * it is displayed): this call renders samples [sample_first, sample_first +
+     * sample_count) of every pixel; sample_count 0 = all the remaining ones.
+     * Sample k of a pixel is the same path whichever pass renders it.          */
+    uint32_t sample_first;
+    uint32_t sample_count;
 } rt_render_cfg;
 
 #define RT_RENDER_COUNT_TRAVERSAL 1u /* fill the node/prim test counters       */
+#define RT_RENDER_ACCUMULATE 2u      /* add to the film passed in instead of
+                                        zeroing it: passes rendered in sample
+                                        order give the one-shot film bit for bit */
 
 /* Counters.  rays_* are the three root closest-hit call sites of
  * R1 integrator.rs:388, R2 integrator.rs:584 (hittable.rs:30),

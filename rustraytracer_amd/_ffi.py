@@ -23,6 +23,7 @@ RT_TEX_SOLID, RT_TEX_CHECKERED = 0, 1
 RT_MAT_MATTE, RT_MAT_LIGHT, RT_MAT_PLASTIC, RT_MAT_GLASS, RT_MAT_METAL, RT_MAT_MIRROR = range(6)
 RT_NO_TEXTURE = 0xFFFFFFFF
 RT_RENDER_COUNT_TRAVERSAL = 1
+RT_RENDER_ACCUMULATE = 2
 RT_COMMIT_HOST_SAH = 0
 RT_COMMIT_DEVICE_LBVH = 1
 RT_INFINITY = 1e308
@@ -90,6 +91,7 @@ class rt_render_cfg(C.Structure):
         ("x0", C.c_uint32), ("y0", C.c_uint32), ("x1", C.c_uint32), ("y1", C.c_uint32),
         ("tile_size", C.c_uint32), ("tile_rank", C.c_uint32), ("tile_world", C.c_uint32),
         ("precision", C.c_uint32), ("paths_in_flight", C.c_uint32), ("flags", C.c_uint32),
+        ("sample_first", C.c_uint32), ("sample_count", C.c_uint32),
     ]
 
 

@@ -65,7 +65,7 @@ class Scene:
 
 
 def make_cfg(width, height, spp, max_depth=MAX_DEPTH, seed=0, window=None, tile_rank=0, tile_world=1,
-             paths_in_flight=0, count_traversal=False):
+             paths_in_flight=0, count_traversal=False, sample_first=0, sample_count=0, accumulate=False):
     cfg = F.rt_render_cfg()
     cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed = width, height, spp, max_depth, seed
     if window:
@@ -74,7 +74,8 @@ def make_cfg(width, height, spp, max_depth=MAX_DEPTH, seed=0, window=None, tile_
     cfg.tile_rank, cfg.tile_world = tile_rank, tile_world
     cfg.precision = 0
     cfg.paths_in_flight = paths_in_flight
-    cfg.flags = F.RT_RENDER_COUNT_TRAVERSAL if count_traversal else 0
+    cfg.flags = (F.RT_RENDER_COUNT_TRAVERSAL if count_traversal else 0) | (F.RT_RENDER_ACCUMULATE if accumulate else 0)
+    cfg.sample_first, cfg.sample_count = sample_first, sample_count  # progressive pass (0, 0 = every sample)
     return cfg
 
 
@@ -112,10 +113,15 @@ class Context:
         """rt_scene_create + set_* + rt_scene_commit_ex; device_build=True builds the BVH on the GPU (row f3)."""
         return GpuScene(self, scene, device_build)
 
-    def render(self, gscene, camera, cfg):
-        """rt_render: returns (rgb_sum[H,W,3] f64, n[H,W] u32, rt_stats)."""
-        rgb = np.zeros((cfg.height, cfg.width, 3), dtype=np.float64)
-        n = np.zeros((cfg.height, cfg.width), dtype=np.uint32)
+    def render(self, gscene, camera, cfg, film=None):
+        """rt_render: returns (rgb_sum[H,W,3] f64, n[H,W] u32, rt_stats).  `film` = (rgb_sum, n) of the earlier
+        passes when cfg carries RT_RENDER_ACCUMULATE (progressive rendering); it is updated in place."""
+        if film is not None:
+            rgb, n = film
+            assert rgb.dtype == np.float64 and n.dtype == np.uint32 and rgb.flags.c_contiguous and n.flags.c_contiguous
+        else:
+            rgb = np.zeros((cfg.height, cfg.width, 3), dtype=np.float64)
+            n = np.zeros((cfg.height, cfg.width), dtype=np.uint32)
         st = F.rt_stats()
         _check(F.lib().rt_render(self._h, gscene._h, camera, C.byref(cfg), rgb.ctypes.data_as(C.c_void_p),
                                  n.ctypes.data_as(C.c_void_p), C.byref(st)))

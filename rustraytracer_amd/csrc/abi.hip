@@ -625,22 +625,28 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
             }
     }
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemsetAsync(d_rgb, 0, sizeof(double) * 3 * (size_t)W * H, stream));
-    HIP_TRY(hipMemsetAsync(d_n, 0, sizeof(uint32_t) * (size_t)W * H, stream));
+    if (!(cfg->flags & RT_RENDER_ACCUMULATE)) {
+        HIP_TRY(hipMemsetAsync(d_rgb, 0, sizeof(double) * 3 * (size_t)W * H, stream));
+        HIP_TRY(hipMemsetAsync(d_n, 0, sizeof(uint32_t) * (size_t)W * H, stream));
+    }
+    // progressive pass: samples [s_first, s_end) of every pixel
+    const uint32_t s_first = std::min(cfg->sample_first, spp);
+    const uint32_t s_end = cfg->sample_count ? (uint32_t)std::min<uint64_t>((uint64_t)s_first + cfg->sample_count, spp) : spp;
+    const uint32_t pass_spp = s_end - s_first;
     HIP_TRY(hipMemsetAsync(c->stats, 0, sizeof(DevStats) * kStatShards, stream));
     const size_t NP = pix.size();
     double kernel_ms = 0.0, trace_ms = 0.0;
     uint64_t trace_launches = 0;
-    if (NP > 0) {
+    if (NP > 0 && pass_spp > 0) {
         // batch shape: PB pixels x ns samples, at most kBatchMax camera samples (film staging size)
         uint32_t PB, ns;
-        if (NP * (size_t)spp <= kBatchMax) {
+        if (NP * (size_t)pass_spp <= kBatchMax) {
             PB = (uint32_t)NP;
-            ns = spp;
+            ns = pass_spp;
         } else if (NP <= kBatchMax) {
             PB = (uint32_t)NP;
             ns = 1;
-            while ((size_t)PB * ns * 2 <= kBatchMax && ns * 2 <= spp) ns *= 2;
+            while ((size_t)PB * ns * 2 <= kBatchMax && ns * 2 <= pass_spp) ns *= 2;
         } else {
             PB = (uint32_t)kBatchMax;
             ns = 1;
@@ -699,16 +705,16 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
         }
         for (size_t pb = 0; pb < NP; pb += PB) {
             const uint32_t npx = (uint32_t)std::min<size_t>(PB, NP - pb);
-            for (uint32_t sb = 0; sb < spp; sb += ns) {
+            for (uint32_t sb = s_first; sb < s_end; sb += ns) {
                 ChunkDesc& ck = job.batch;
                 ck.n_pixels = npx;
-                ck.n_samples = ns;
+                ck.n_samples = std::min(ns, s_end - sb);
                 ck.pixel_base = (uint32_t)pb;
                 ck.sample_base = sb;
                 ck.width = W;
                 ck.height = H;
                 ck.seed = cfg->seed;
-                job.batch_total = (unsigned long long)npx * ns;
+                job.batch_total = (unsigned long long)npx * ck.n_samples;
                 // the lanes start after everything queued on the caller's stream so far (film zeroing,
                 // pixel list upload, the previous batch's resolve)
                 HIP_TRY(hipMemsetAsync(c->batch, 0, sizeof(BatchCtl), stream));
@@ -825,6 +831,20 @@ int rt_render(rt_context* c, rt_scene* s, const rt_camera* cam, const rt_render_
     if (e != hipSuccess) {
         (void)hipFree(d_rgb);
         return fail(RT_ERR_OOM, "hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    if (cfg->flags & RT_RENDER_ACCUMULATE) {  // progressive pass: continue from the caller's film
+        if (!rgb_sum || !n) {
+            (void)hipFree(d_rgb);
+            (void)hipFree(d_n);
+            return fail(RT_ERR_INVALID_ARG, "RT_RENDER_ACCUMULATE needs both film pointers");
+        }
+        e = hipMemcpy(d_rgb, rgb_sum, npix * 3 * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_n, n, npix * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(d_rgb);
+            (void)hipFree(d_n);
+            return fail(RT_ERR_HIP, "film upload failed: %s", hipGetErrorString(e));
+        }
     }
     rc = render_impl(c, s, cam, cfg, d_rgb, d_n, c->stream, stats);
     if (rc == RT_OK && rgb_sum) {

@@ -375,3 +375,30 @@ def test_device_built_bvh_renders_the_same_film(gpu_ctx):
         assert np.array_equal(rd, ro) and rmse(rd, nd, ro, no) < RMSE_TOL
         g_host.close()
         g_dev.close()
+
+
+def test_progressive_passes_give_the_one_shot_film(gpu_ctx):
+    """next-row f4 (render.rs:161-324): the picture is refined pass by pass; passes in sample order sum to
+    the one-shot film bit for bit (k_resolve continues each pixel's running sum)."""
+    sc = rr.cornell_box_statue(mesh_faces=8000, variant=3)
+    gs = gpu_ctx.upload(sc)
+    W, H, spp = 48, 40, 16
+    full, nfull, st_full = gpu_ctx.render(gs, sc.camera, rr.make_cfg(W, H, spp, seed=9))
+    film = (np.zeros((H, W, 3)), np.zeros((H, W), dtype=np.uint32))
+    rays = 0
+    for first, count in ((0, 1), (1, 3), (4, 4), (8, 0)):   # 1 + 3 + 4 + the remaining 8
+        cfg = rr.make_cfg(W, H, spp, seed=9, sample_first=first, sample_count=count, accumulate=True)
+        _, _, st = gpu_ctx.render(gs, sc.camera, cfg, film=film)
+        rays += st.rays
+        if first == 0:   # after the first pass every pixel has exactly one sample (render.rs:174-262)
+            assert (film[1] == 1).all()
+            one, none_, _ = gpu_ctx.render(gs, sc.camera, rr.make_cfg(W, H, spp, seed=9, sample_count=1))
+            assert np.array_equal(one, film[0])
+    assert np.array_equal(film[0], full) and np.array_equal(film[1], nfull) and rays == st_full.rays
+    ro, no, _ = O.OracleScene(sc).render(sc.camera, rr.make_cfg(W, H, spp, seed=9))
+    assert np.array_equal(film[0], ro) and rmse(film[0], film[1], ro, no) < RMSE_TOL
+    # an empty pass is a no-op; accumulate needs both film pointers
+    before = film[0].copy()
+    gpu_ctx.render(gs, sc.camera, rr.make_cfg(W, H, spp, seed=9, sample_first=16, accumulate=True), film=film)
+    assert np.array_equal(before, film[0])
+    gs.close()

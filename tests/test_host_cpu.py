@@ -87,7 +87,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(F.rt_light) == 48
     assert C.sizeof(F.rt_camera) == 15 * 8 + 9 * 8
     assert C.sizeof(F.rt_ray) == 64 and C.sizeof(F.rt_hit) == 16
-    assert C.sizeof(F.rt_render_cfg) == 64
+    assert C.sizeof(F.rt_render_cfg) == 72
     assert C.sizeof(F.rt_stats) == 8 * 8 + 16 + 8 + 32
 
 
