@@ -110,10 +110,15 @@ typedef struct rt_mesh {
     uint64_t n_p, n_n, n_uv, n_ind;
 } rt_mesh;
 
-/* src/material.rs:519-539; only the kinds the hot-path scope covers.          */
+/* src/material.rs:519-539; the kinds the hot-path scope covers.                */
 typedef enum rt_texture_kind {
     RT_TEX_SOLID = 0,     /* color                                             */
-    RT_TEX_CHECKERED = 1  /* odd, even texture ids + frequency                 */
+    RT_TEX_CHECKERED = 1, /* odd, even texture ids + frequency                 */
+    RT_TEX_HDR = 2        /* Texture::Hdr (next-row f4): width x height texels
+                             of 4 bytes, row-major from the top: what
+                             image::hdr::to_rgbe8(data[i]) returns for texel i
+                             (c[0], c[1], c[2], e), which is all that
+                             Texture::get_value reads (material.rs:570-587)    */
 } rt_texture_kind;
 
 typedef struct rt_texture {
@@ -123,6 +128,8 @@ typedef struct rt_texture {
     uint32_t reserved;
     double color[3];
     double frequency;
+    const uint8_t* rgbe;  /* RT_TEX_HDR only, copied by rt_scene_set_textures  */
+    uint32_t width, height;
 } rt_texture;
 
 /* src/material.rs:17-73 */
@@ -131,7 +138,8 @@ typedef enum rt_material_kind {
     RT_MAT_LIGHT = 1,    /* no lobes                                           */
     RT_MAT_PLASTIC = 2,  /* tex[0]=k_d, tex[1]=k_s; f[0]=roughness             */
     RT_MAT_GLASS = 3,    /* tex[0]=k_r, tex[1]=k_t; f[0]=u_rough f[1]=v_rough
-                            f[2]=index (only smooth supported)                 */
+                            f[2]=index; rough = MicrofacetReflection +
+                            MicrofacetTransmission (material.rs:153-189)       */
     RT_MAT_METAL = 4,    /* tex[0]=eta, tex[1]=k, tex[2]=rough, tex[3]=urough,
                             tex[4]=vrough (RT_NO_TEXTURE = usize::MAX)         */
     RT_MAT_MIRROR = 5    /* tex[0]=color                                       */
@@ -147,16 +155,28 @@ typedef struct rt_material {
     double f[3];
 } rt_material;
 
-/* src/light.rs:59-69: only Light::Diffuse is in scope.                        */
-typedef enum rt_light_kind { RT_LIGHT_DIFFUSE = 0 } rt_light_kind;
+/* src/light.rs:59-93: Light::Diffuse, and Light::Infinite (next-row f4).       */
+typedef enum rt_light_kind {
+    RT_LIGHT_DIFFUSE = 0,
+    RT_LIGHT_INFINITE = 1 /* environment map: tex_index = an RT_TEX_HDR texture,
+                             xform_index = to_world (-1 = identity),
+                             world_radius = 10000 in make_infinite_light
+                             (light.rs:608-638); at most one per scene.  The
+                             library rebuilds the Distribution2D of
+                             make_infinite_light from the texture at commit.   */
+} rt_light_kind;
 
 typedef struct rt_light {
     uint32_t kind;
-    uint32_t prim_index;
-    uint32_t two_sided;
+    uint32_t prim_index;  /* Diffuse                                           */
+    uint32_t two_sided;   /* Diffuse                                           */
+    uint32_t tex_index;   /* Infinite                                          */
+    int32_t xform_index;  /* Infinite                                          */
     uint32_t reserved;
-    double color[3];
-    double area;          /* Primitive::area() at construction (light.rs:603)  */
+    double color[3];      /* Diffuse                                           */
+    double area;          /* Diffuse: Primitive::area() at construction
+                             (light.rs:603)                                    */
+    double world_radius;  /* Infinite                                          */
 } rt_light;
 
 /* Flattened `Objects` (src/geometry.rs:13-21), caller-owned.                  */

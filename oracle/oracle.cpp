@@ -63,13 +63,31 @@ struct BvhNode {
     int32_t prim;         // leaf primitive or -1
 };
 
+// distribution.rs:4-91 Distribution1D over `n` values func[0..n) (a window of the image, see Dist2D)
+struct Dist1D {
+    const double* func = nullptr;
+    size_t n = 0;
+    std::vector<double> cdf;
+    double func_int = 0.0;
+};
+// distribution.rs:93-150 Distribution2D
+struct Dist2D {
+    std::vector<double> img;         // light.rs:615-626: luminance * sin(theta), (2w) x (2h)
+    std::vector<Dist1D> p_cond_v;
+    std::vector<double> marginal_func;
+    Dist1D p_marginal;
+};
+
 struct Scene {
     std::vector<Mesh> meshes;
     std::vector<rt_primitive> prims;
     std::vector<rt_xform> xforms;
     std::vector<rt_material> mats;
     std::vector<rt_texture> texs;
+    std::vector<std::vector<uint8_t>> hdr;  // texel copies of the RT_TEX_HDR textures (texs[i].rgbe points here)
     std::vector<rt_light> lights;
+    int32_t env_light = -1;  // index of the Light::Infinite, if any
+    Dist2D env_dist;
     std::vector<BvhNode> nodes;
     int32_t root = -1;
 };
@@ -563,8 +581,31 @@ static bool closest_hit(const Scene& sc, int mode, const Ray& ray, double tmin, 
 
 // ------------------------------------------------------------- textures
 // material.rs:542-565 (Q19).  The recursion follows Checkered -> even/odd ids.
+// Rust `f64 as u32`: saturating, NaN -> 0
+static uint32_t sat_u32(double x) {
+    if (!(x > 0.0)) return 0u;
+    if (x >= 4294967295.0) return 4294967295u;
+    return (uint32_t)x;
+}
+static size_t sat_usize(double x) {
+    if (!(x > 0.0)) return 0;
+    if (x >= 18446744073709551615.0) return (size_t)-1;
+    return (size_t)x;
+}
+// material.rs:570-587 Texture::Hdr arm of get_value; texels arrive as to_rgbe8(data[i]) (rt_abi.h)
+static V3 hdr_value(const rt_texture& t, double u, double v) {
+    const uint32_t width = t.width, height = t.height;
+    uint32_t x = sat_u32(std::round((1.0 - u) * (double)width));
+    uint32_t y = sat_u32(std::round(v * (double)height));
+    x = x % width;
+    y = y % height;
+    const uint8_t* px = t.rgbe + 4 * ((size_t)y * width + x);
+    const double sc = std::ldexp(1.0, (int)px[3] - 128);  // (2f64).powi(e - 128)
+    return v3(((double)px[0] + 0.5) * sc / 256.0, ((double)px[1] + 0.5) * sc / 256.0, ((double)px[2] + 0.5) * sc / 256.0);
+}
 static V3 texture_value(const Scene& sc, uint32_t index, double u, double v, int depth = 0) {
     const rt_texture& t = sc.texs[index];
+    if (t.kind == RT_TEX_HDR) return hdr_value(t, u, v);
     if (t.kind == RT_TEX_CHECKERED && depth < 8) {
         double mult = dm_sin(t.frequency * u * 2.0 * PI) * dm_sin(t.frequency * v * 2.0 * PI);
         if (mult < 0.0) return texture_value(sc, t.even, u, v, depth + 1);
@@ -615,7 +656,7 @@ static V3 fr_conductor(double cos_theta_i, V3 eta, V3 eta_k) {
 }
 
 // ------------------------------------------------------ BxDF / BSDF
-enum LobeKind { LOBE_LAMBERT = 0, LOBE_MICROFACET = 1, LOBE_FRESNEL_SPECULAR = 2, LOBE_SPECULAR_REFL = 3 };
+enum LobeKind { LOBE_LAMBERT = 0, LOBE_MICROFACET = 1, LOBE_FRESNEL_SPECULAR = 2, LOBE_SPECULAR_REFL = 3, LOBE_MICRO_TRANS = 4 };
 enum FresnelKind { FR_DIELECTRIC = 0, FR_CONDUCTOR = 1, FR_NOOP = 2 };
 
 struct Lobe {
@@ -627,7 +668,7 @@ struct Lobe {
     double eta_i, eta_t;  // FresnelDielectric
     V3 eta, k;            // FresnelConductor
     double alpha_x, alpha_y;
-    double eta_a, eta_b;  // FresnelSpecular
+    double eta_a, eta_b;  // FresnelSpecular, MicrofacetTransmission
 };
 
 struct Bsdf {  // bsdf.rs:13-20
@@ -763,6 +804,22 @@ static V3 bxdf_f(const Lobe& l, V3 wo, V3 wi) {
             V3 comp1 = l.color * tr_d(l.alpha_x, l.alpha_y, wh) * tr_g(l.alpha_x, l.alpha_y, wo, wi);
             return cmul(comp1, f * (1.0 / (4.0 * cos_i * cos_o)));
         }
+        case LOBE_MICRO_TRANS: {  // bxdf.rs:393-441 (mode == RADIANCE)
+            if (same_hemisphere(wo, wi)) return black();
+            double cos_theta_o = wo.z, cos_theta_i = wi.z;
+            if (cos_theta_i == 0.0 || cos_theta_o == 0.0) return black();
+            double eta = wo.z > 0.0 ? l.eta_b / l.eta_a : l.eta_a / l.eta_b;
+            V3 wh = normalize(wo + wi * eta);
+            if (wh.z < 0.0) wh = -wh;
+            if (dot(wo, wh) * dot(wi, wh) > 0.0) return black();
+            V3 f = fresnel_evaluate(l, dot(wo, wh));
+            double sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
+            double factor = 1.0 / eta;
+            V3 c = cmul(white() - f, l.color);
+            return c * std::fabs(tr_d(l.alpha_x, l.alpha_y, wh) * tr_g(l.alpha_x, l.alpha_y, wo, wi) * eta * eta *
+                                 std::fabs(dot(wi, wh)) * std::fabs(dot(wo, wh)) * factor * factor /
+                                 (cos_theta_i * cos_theta_o * sqrt_denom * sqrt_denom));
+        }
         default: return black();
     }
 }
@@ -775,6 +832,15 @@ static double bxdf_pdf(const Lobe& l, V3 wo, V3 wi) {
             if (!same_hemisphere(wo, wi)) return 0.0;
             V3 wh = normalize(wo + wi);
             return tr_pdf(l.alpha_x, l.alpha_y, wo, wh) / (4.0 * dot(wo, wh));
+        }
+        case LOBE_MICRO_TRANS: {  // bxdf.rs:742-763
+            if (same_hemisphere(wo, wi)) return 0.0;
+            double eta = wo.z > 0.0 ? l.eta_b / l.eta_a : l.eta_a / l.eta_b;
+            V3 wh = normalize(wo + wi * eta);
+            if (dot(wo, wh) * dot(wi, wh) > 0.0) return 0.0;
+            double sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
+            double dwh_dwi = std::fabs(eta * eta * dot(wi, wh)) / (sqrt_denom * sqrt_denom);
+            return tr_pdf(l.alpha_x, l.alpha_y, wo, wh) * dwh_dwi;
         }
         default: return 0.0;
     }
@@ -822,6 +888,18 @@ static void bxdf_sample_f(const Lobe& l, V3 wo, double u0, double u1, Rng& rng, 
                 return;
             }
             f = black(); wi = black(); pdf = 0.0;
+            return;
+        }
+        case LOBE_MICRO_TRANS: {  // bxdf.rs:608-638
+            if (wo.z == 0.0) { f = black(); wi = black(); pdf = 0.0; return; }
+            V3 wh = tr_sample_wh(l.alpha_x, l.alpha_y, wo, u0, u1);
+            if (dot(wo, wh) < 0.0) { f = black(); wi = black(); pdf = 0.0; return; }
+            double eta = wo.z > 0.0 ? l.eta_a / l.eta_b : l.eta_b / l.eta_a;
+            V3 t;
+            if (!refract(wo, wh, eta, t)) { f = black(); wi = black(); pdf = 0.0; return; }
+            wi = t;
+            pdf = bxdf_pdf(l, wo, wi);
+            f = bxdf_f(l, wo, wi);
             return;
         }
         case LOBE_SPECULAR_REFL: {  // bxdf.rs:543-552
@@ -976,15 +1054,41 @@ static int compute_scattering(const Scene& sc, const Hit& h, Bsdf& b) {
             V3 t = texture_value(sc, m.tex[1], h.u, h.v);
             bsdf_init(b, h);
             if (is_black(r) && is_black(t)) break;
-            // smooth glass only (urough == vrough == 0), allow_lobes = true -> FresnelSpecular
-            Lobe l{};
-            l.kind = LOBE_FRESNEL_SPECULAR;
-            l.type = RT_BSDF_TRANSMISSION | RT_BSDF_REFLECTION | RT_BSDF_SPECULAR;
-            l.color = r;
-            l.t = t;
-            l.eta_a = m.f[2];
-            l.eta_b = 1.0;
-            b.lobes[b.n++] = l;
+            double urough = m.f[0], vrough = m.f[1];
+            if (urough == 0.0 && vrough == 0.0) {  // is_specular && allow_lobes -> FresnelSpecular
+                Lobe l{};
+                l.kind = LOBE_FRESNEL_SPECULAR;
+                l.type = RT_BSDF_TRANSMISSION | RT_BSDF_REFLECTION | RT_BSDF_SPECULAR;
+                l.color = r;
+                l.t = t;
+                l.eta_a = m.f[2];
+                l.eta_b = 1.0;
+                b.lobes[b.n++] = l;
+                break;
+            }
+            // material.rs:161-189: MicrofacetReflection + MicrofacetTransmission over one TrowbridgeReitz
+            if (m.remap_roughness) {
+                urough = tr_roughness_to_alpha(urough);
+                vrough = tr_roughness_to_alpha(vrough);
+            }
+            if (!is_black(r)) {
+                Lobe l = make_microfacet(r, urough, vrough);
+                l.fresnel = FR_DIELECTRIC;
+                l.eta_i = m.f[2];
+                l.eta_t = 1.0;
+                b.lobes[b.n++] = l;
+            }
+            if (!is_black(t)) {
+                Lobe l = make_microfacet(t, urough, vrough);  // same make_trowbridge_reitz clamp
+                l.kind = LOBE_MICRO_TRANS;
+                l.type = RT_BSDF_TRANSMISSION | RT_BSDF_GLOSSY;
+                l.fresnel = FR_DIELECTRIC;  // bxdf.rs:957-970: FresnelDielectric{eta_a, eta_b}
+                l.eta_i = m.f[2];
+                l.eta_t = 1.0;
+                l.eta_a = m.f[2];
+                l.eta_b = 1.0;
+                b.lobes[b.n++] = l;
+            }
             break;
         }
         case RT_MAT_METAL: {
@@ -1097,6 +1201,114 @@ static double prim_pdf(const Scene& sc, const rt_primitive& pr, const Hit& rec, 
     return norm2(dist) / (prim_area(sc, pr) * std::fabs(dot(nh.n, -dir)));
 }
 
+// ------------------------------------------------- Distribution1D / 2D
+// distribution.rs:27-55 make_distribution
+static void dist1d_make(Dist1D& d, const double* f, size_t n) {
+    d.func = f;
+    d.n = n;
+    d.cdf.assign(n + 1, 0.0);
+    for (size_t i = 1; i < n + 1; i++) d.cdf[i] = d.cdf[i - 1] + f[i - 1] / (double)n;
+    d.func_int = d.cdf[n];
+    if (d.func_int == 0.0) {
+        for (size_t i = 1; i < n + 1; i++) d.cdf[i] = (double)i / (double)n;
+    } else {
+        for (size_t i = 1; i < n + 1; i++) d.cdf[i] = d.cdf[i] / d.func_int;
+    }
+}
+// distribution.rs:152-166 find_interval with pred = cdf[index] <= u
+static size_t find_interval(const std::vector<double>& cdf, double u) {
+    const size_t size = cdf.size();
+    size_t first = 0, len = size;
+    while (len > 0) {
+        size_t half = len >> 1, middle = first + half;
+        if (cdf[middle] <= u) {
+            first = middle + 1;
+            len = len - half - 1;
+        } else {
+            len = half;
+        }
+    }
+    // clamp((first - 1) as f64, 0, size - 2) as usize; first == 0 (u < 0 or NaN) wraps in release builds
+    double x = first == 0 ? 18446744073709551615.0 : (double)(first - 1);
+    return sat_usize(clampd(x, 0.0, (double)(size - 2)));
+}
+// distribution.rs:64-78 sample_continuous
+static void dist1d_sample(const Dist1D& d, double u, double& x, double& pdf, size_t& offset) {
+    offset = find_interval(d.cdf, u);
+    double du = u - d.cdf[offset];
+    if (d.cdf[offset + 1] - d.cdf[offset] > 0.0) du = du / (d.cdf[offset + 1] - d.cdf[offset]);
+    pdf = d.func_int > 0.0 ? d.func[offset] / d.func_int : 0.0;
+    x = ((double)offset + du) / (double)d.n;
+}
+// light.rs:608-638 make_infinite_light's image + distribution.rs:115-128 make_distribution_2d.
+// The reference slices row v as f[v .. v + nu] (not f[v * nu ..]): restated literally.
+static void env_dist_make(Scene& sc, const rt_texture& t) {
+    Dist2D& d = sc.env_dist;
+    const size_t width = (size_t)t.width * 2, height = (size_t)t.height * 2;
+    d.img.assign(width * height, 0.0);
+    for (size_t v = 0; v < height; v++) {
+        double vp = ((double)v + 0.5) / (double)height;
+        double sin_theta = dm_sin(PI * ((double)v + 0.5) / (double)height);
+        for (size_t u = 0; u < width; u++) {
+            double up = (double)u / (double)width;
+            V3 color = hdr_value(t, up, vp);
+            double lum = 0.2126 * color.x + 0.7152 * color.y + 0.0722 * color.z;  // util.rs:169-171
+            d.img[u + v * width] = lum * sin_theta;
+        }
+    }
+    d.p_cond_v.resize(height);
+    d.marginal_func.resize(height);
+    for (size_t v = 0; v < height; v++) {
+        dist1d_make(d.p_cond_v[v], d.img.data() + v, width);
+        d.marginal_func[v] = d.p_cond_v[v].func_int;
+    }
+    dist1d_make(d.p_marginal, d.marginal_func.data(), height);
+}
+// distribution.rs:133-137
+static void dist2d_sample(const Dist2D& d, double u0, double u1, double& x0, double& x1, double& pdf) {
+    double pdf1, pdf0;
+    size_t v, off;
+    dist1d_sample(d.p_marginal, u1, x1, pdf1, v);
+    dist1d_sample(d.p_cond_v[v], u0, x0, pdf0, off);
+    pdf = pdf1 * pdf0;
+}
+// distribution.rs:139-145
+static double dist2d_pdf(const Dist2D& d, double p0, double p1) {
+    size_t iu = sat_usize(p0 * (double)d.p_cond_v[0].n);
+    iu = std::min(iu, d.p_cond_v[0].n - 1);
+    size_t iv = sat_usize(p1 * (double)d.p_marginal.n);
+    iv = std::min(iv, d.p_marginal.n - 1);
+    return d.p_cond_v[iv].func[iu] / d.p_marginal.func_int;
+}
+
+// ------------------------------------------------------ Light::Infinite
+static const double INV_2PI = 1.0 / (2.0 * PI);  // consts.rs:42
+static double spherical_theta(V3 v) { return dm_acos(clampd(v.y, -1.0, 1.0)); }  // util.rs:153-155
+static double spherical_phi(V3 v) {                                              // util.rs:160-167
+    double p = dm_atan2(v.z, v.x);
+    return p < 0.0 ? p + 2.0 * PI : p;
+}
+static V3 light_to_world(const Scene& sc, const rt_light& lt, V3 v) {
+    return lt.xform_index >= 0 ? xf_vector(sc.xforms[lt.xform_index].fwd, v) : v;
+}
+static V3 light_to_obj(const Scene& sc, const rt_light& lt, V3 v) {
+    return lt.xform_index >= 0 ? xf_vector(sc.xforms[lt.xform_index].inv, v) : v;
+}
+// light.rs:499-512 Light::le (black for every other kind)
+static V3 light_le(const Scene& sc, const rt_light& lt, V3 dir) {
+    if (lt.kind != RT_LIGHT_INFINITE) return black();
+    V3 w = normalize(light_to_obj(sc, lt, dir));
+    return texture_value(sc, lt.tex_index, spherical_phi(w) * INV_2PI, spherical_theta(w) * INV_PI);
+}
+// light.rs:285-294 pdf_li (uses to_world, as the reference does)
+static double infinite_pdf_li(const Scene& sc, const rt_light& lt, V3 wi) {
+    V3 w = light_to_world(sc, lt, wi);
+    double theta = spherical_theta(w), phi = spherical_phi(w);
+    double sin_theta = dm_sin(theta);
+    if (sin_theta == 0.0) return 0.0;
+    return dist2d_pdf(sc.env_dist, phi * INV_2PI, theta * INV_PI) / (2.0 * PI * PI * sin_theta);
+}
+
 // ------------------------------------------------------------ integrator
 struct Ctx {
     const Scene& sc;
@@ -1114,6 +1326,13 @@ static bool unoccluded(Ctx& cx, V3 p0, V3 p1, int32_t light_prim) {
     if (!closest_hit(cx.sc, cx.mode, ray, 0.0, INF, h, &cx.c)) return false;  // infinite_light == false
     return h.prim == light_prim;
 }
+static bool unoccluded_infinite(Ctx& cx, V3 p0, V3 p1) {  // unoccluded(true): only a miss is unoccluded
+    V3 dir = p1 - p0;
+    Ray ray{p0 + dir * SMALL, dir};
+    Hit h;
+    cx.c.r2++;
+    return !closest_hit(cx.sc, cx.mode, ray, 0.0, INF, h, &cx.c);
+}
 
 // integrator.rs:655-659
 static double power_heuristic(int nf, double f_pdf, int ng, double g_pdf) {
@@ -1126,35 +1345,64 @@ static V3 estimate_direct(Ctx& cx, const Hit& rec, const Bsdf& bsdf, double us0,
                           double ul0, double ul1, Rng& rng) {
     const Scene& sc = cx.sc;
     const rt_light& lt = sc.lights[light_idx];
-    const rt_primitive& lp = sc.prims[lt.prim_index];
+    const bool infinite = lt.kind == RT_LIGHT_INFINITE;
+    static const rt_primitive no_prim{};
+    const rt_primitive& lp = infinite ? no_prim : sc.prims[lt.prim_index];
     const uint8_t flags = RT_BSDF_ALL - RT_BSDF_SPECULAR;
     V3 ld = black();
-    // Light::sample_li (Diffuse) -> Primitive::sample (Q9)
     V3 sp, sn;
     double light_pdf;
-    sample_area(sc, lp, ul0, ul1, sp, sn, light_pdf);
-    V3 wi_raw = sp - rec.p;
-    if (norm2(wi_raw) == 0.0) {
-        light_pdf = 0.0;
-    } else {
-        V3 wn = normalize(wi_raw);
-        light_pdf = light_pdf * norm2(rec.p - sp) / std::fabs(dot(sn, -wn));
-    }
     V3 wi, color;
-    if (light_pdf == 0.0 || norm2(rec.p - sp) == 0.0) {
-        light_pdf = 0.0;
-        wi = normalize(black());
-        color = v3(lt.color[0], lt.color[1], lt.color[2]);
+    if (infinite) {
+        // Light::sample_li, Infinite arm (light.rs:204-245)
+        double uv0, uv1, map_pdf;
+        dist2d_sample(sc.env_dist, ul0, ul1, uv0, uv1, map_pdf);
+        if (map_pdf == 0.0) {
+            wi = normalize(black());
+            light_pdf = 0.0;
+            color = black();
+            sp = black();
+        } else {
+            double theta = uv1 * PI, phi = uv0 * 2.0 * PI;
+            double cos_theta = dm_cos(theta), sin_theta = dm_sin(theta);
+            double cos_phi = dm_cos(phi), sin_phi = dm_sin(phi);
+            V3 v = v3(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta);
+            V3 wiv = light_to_world(sc, lt, v);
+            light_pdf = map_pdf / (2.0 * PI * PI * sin_theta);
+            if (sin_theta == 0.0) light_pdf = 0.0;
+            sp = rec.p + wiv * (2.0 * lt.world_radius);  // Visibility's far end
+            color = texture_value(sc, lt.tex_index, uv0, uv1);
+            wi = normalize(wiv);
+        }
     } else {
-        wi = normalize(sp - rec.p);
-        color = light_l(lt, sn, -wi);
+        // Light::sample_li (Diffuse) -> Primitive::sample (Q9)
+        sample_area(sc, lp, ul0, ul1, sp, sn, light_pdf);
+        V3 wi_raw = sp - rec.p;
+        if (norm2(wi_raw) == 0.0) {
+            light_pdf = 0.0;
+        } else {
+            V3 wn = normalize(wi_raw);
+            light_pdf = light_pdf * norm2(rec.p - sp) / std::fabs(dot(sn, -wn));
+        }
+        if (light_pdf == 0.0 || norm2(rec.p - sp) == 0.0) {
+            light_pdf = 0.0;
+            wi = normalize(black());
+            color = v3(lt.color[0], lt.color[1], lt.color[2]);
+        } else {
+            wi = normalize(sp - rec.p);
+            color = light_l(lt, sn, -wi);
+        }
     }
     double scattering_pdf;
     if (light_pdf > 0.0 && !is_black(color)) {
         V3 f = bsdf_f(bsdf, rec.wo, wi, flags) * std::fabs(dot(wi, rec.sh_n));
         scattering_pdf = bsdf_pdf(bsdf, rec.wo, wi, flags);
         if (!is_black(f)) {
-            if (!unoccluded(cx, rec.p, sp, (int32_t)lt.prim_index)) color = black();
+            if (infinite) {
+                if (!unoccluded_infinite(cx, rec.p, sp)) color = black();
+            } else if (!unoccluded(cx, rec.p, sp, (int32_t)lt.prim_index)) {
+                color = black();
+            }
             if (!is_black(color)) {
                 double weight = power_heuristic(1, light_pdf, 1, scattering_pdf);
                 ld = ld + cmul(f, color) * (weight / light_pdf);
@@ -1172,7 +1420,7 @@ static V3 estimate_direct(Ctx& cx, const Hit& rec, const Bsdf& bsdf, double us0,
         if (!is_black(f) && spdf > 0.0) {
             double weight = 1.0;
             if (!sampled_specular) {
-                light_pdf = prim_pdf(sc, lp, rec, wi2);  // Light::pdf_li
+                light_pdf = infinite ? infinite_pdf_li(sc, lt, wi2) : prim_pdf(sc, lp, rec, wi2);  // Light::pdf_li
                 if (light_pdf == 0.0) return ld;
                 weight = power_heuristic(1, spdf, 1, light_pdf);
             }
@@ -1183,6 +1431,8 @@ static V3 estimate_direct(Ctx& cx, const Hit& rec, const Bsdf& bsdf, double us0,
             if (closest_hit(sc, cx.mode, nr, SMALL, INF, nh, &cx.c)) {
                 int32_t li = sc.prims[nh.prim].light_index;
                 if (li >= 0 && li == light_idx) col = light_l(sc.lights[li], nh.n, -wi2);  // new_record.le(-wi)
+            } else {
+                col = light_le(sc, lt, wi2);  // light.le(&new_ray): non-black only for Light::Infinite
             }
             if (!is_black(col)) ld = ld + cmul(f, col) * (weight / spdf);
         }
@@ -1216,7 +1466,9 @@ static V3 li(Ctx& cx, Ray ray, Rng& rng) {
                 int32_t li_ = sc.prims[rec.prim].light_index;
                 if (li_ >= 0) l = l + cmul(light_l(sc.lights[li_], rec.n, -ray.d), beta);  // record.le(-ray.dir)
             }
-            // miss: Light::le is black for every non-Infinite light (light.rs:499-512)
+            else {
+                for (const rt_light& lt : sc.lights) l = l + cmul(light_le(sc, lt, ray.d), beta);  // integrator.rs:403-407
+            }
         }
         if (!is_some || bounces >= cx.max_depth) break;
         Bsdf bsdf;
@@ -1312,6 +1564,24 @@ int oracle_scene_create(const rt_scene_desc* d, oracle_scene** out) {
     sc.mats.assign(d->materials, d->materials + d->n_materials);
     sc.texs.assign(d->textures, d->textures + d->n_textures);
     if (d->n_lights) sc.lights.assign(d->lights, d->lights + d->n_lights);
+    sc.hdr.resize(sc.texs.size());
+    for (size_t i = 0; i < sc.texs.size(); i++) {
+        rt_texture& t = sc.texs[i];
+        if (t.kind != RT_TEX_HDR) continue;
+        if (!t.rgbe || t.width == 0 || t.height == 0) { delete h; return RT_ERR_INVALID_ARG; }
+        sc.hdr[i].assign(t.rgbe, t.rgbe + (size_t)t.width * t.height * 4);
+        t.rgbe = sc.hdr[i].data();
+    }
+    for (size_t i = 0; i < sc.lights.size(); i++) {
+        const rt_light& lt = sc.lights[i];
+        if (lt.kind != RT_LIGHT_INFINITE) continue;
+        if (sc.env_light >= 0 || lt.tex_index >= sc.texs.size() || sc.texs[lt.tex_index].kind != RT_TEX_HDR) {
+            delete h;
+            return RT_ERR_UNSUPPORTED;
+        }
+        sc.env_light = (int32_t)i;
+        env_dist_make(sc, sc.texs[lt.tex_index]);
+    }
     if (!sc.prims.empty()) {
         std::vector<int32_t> idx(sc.prims.size());
         for (size_t i = 0; i < idx.size(); i++) idx[i] = (int32_t)i;
@@ -1521,6 +1791,47 @@ void oracle_microfacet_f_pdf(double ax, double ay, const double* eta, const doub
     V3 r = bxdf_f(l, v3(wo[0], wo[1], wo[2]), v3(wi[0], wi[1], wi[2]));
     f[0] = r.x; f[1] = r.y; f[2] = r.z;
     *pdf = bxdf_pdf(l, v3(wo[0], wo[1], wo[2]), v3(wi[0], wi[1], wi[2]));
+}
+// MicrofacetTransmission lobe (next-row f4), local frame: f, pdf for (wo, wi) and one sample_f draw
+void oracle_micro_trans(double ax, double ay, double eta, const double* color, const double* wo, const double* wi,
+                        double u0, double u1, double* f, double* pdf, double* s_wi, double* s_f, double* s_pdf) {
+    Lobe l = make_microfacet(v3(color[0], color[1], color[2]), ax, ay);
+    l.kind = LOBE_MICRO_TRANS;
+    l.type = RT_BSDF_TRANSMISSION | RT_BSDF_GLOSSY;
+    l.fresnel = FR_DIELECTRIC;
+    l.eta_i = eta; l.eta_t = 1.0;
+    l.eta_a = eta; l.eta_b = 1.0;
+    V3 o = v3(wo[0], wo[1], wo[2]), i = v3(wi[0], wi[1], wi[2]);
+    V3 r = bxdf_f(l, o, i);
+    f[0] = r.x; f[1] = r.y; f[2] = r.z;
+    *pdf = bxdf_pdf(l, o, i);
+    Rng rng(0, 0, 0);
+    V3 sf, swi;
+    bxdf_sample_f(l, o, u0, u1, rng, sf, swi, *s_pdf);
+    s_wi[0] = swi.x; s_wi[1] = swi.y; s_wi[2] = swi.z;
+    s_f[0] = sf.x; s_f[1] = sf.y; s_f[2] = sf.z;
+}
+// Light::Infinite of the scene (next-row f4).  what: 0 sample (in = u0,u1; out = uv0, uv1, map_pdf),
+// 1 map pdf at (in = p0,p1), 2 le(dir), 3 pdf_li(dir), 4 table sizes (out = nu, nv, marg_int)
+int oracle_env(const oracle_scene* s, int what, const double* in, double* out) {
+    const Scene& sc = s->sc;
+    if (sc.env_light < 0) return RT_ERR_STATE;
+    const rt_light& lt = sc.lights[sc.env_light];
+    switch (what) {
+        case 0: dist2d_sample(sc.env_dist, in[0], in[1], out[0], out[1], out[2]); break;
+        case 1: out[0] = dist2d_pdf(sc.env_dist, in[0], in[1]); break;
+        case 2: {
+            V3 c = light_le(sc, lt, v3(in[0], in[1], in[2]));
+            out[0] = c.x; out[1] = c.y; out[2] = c.z;
+            break;
+        }
+        case 3: out[0] = infinite_pdf_li(sc, lt, v3(in[0], in[1], in[2])); break;
+        default:
+            out[0] = (double)sc.env_dist.p_cond_v[0].n;
+            out[1] = (double)sc.env_dist.p_marginal.n;
+            out[2] = sc.env_dist.p_marginal.func_int;
+    }
+    return RT_OK;
 }
 double oracle_prim_area(const oracle_scene* s, int32_t prim) { return prim_area(s->sc, s->sc.prims[prim]); }
 double oracle_prim_pdf(const oracle_scene* s, int32_t prim, const double* p, const double* dir) {

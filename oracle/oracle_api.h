@@ -58,6 +58,9 @@ int oracle_refract(const double* v, const double* n, double eta, double* out);
 void oracle_lambert_f_pdf(const double* color, const double* wo, const double* wi, double* f, double* pdf);
 void oracle_microfacet_f_pdf(double ax, double ay, const double* eta, const double* k, const double* wo,
                              const double* wi, double* f, double* pdf);
+void oracle_micro_trans(double ax, double ay, double eta, const double* color, const double* wo, const double* wi,
+                        double u0, double u1, double* f, double* pdf, double* s_wi, double* s_f, double* s_pdf);
+int oracle_env(const oracle_scene* s, int what, const double* in, double* out);
 double oracle_prim_area(const oracle_scene* s, int32_t prim);
 double oracle_prim_pdf(const oracle_scene* s, int32_t prim, const double* p, const double* dir);
 void oracle_texture_value(const oracle_scene* s, uint32_t tex, double u, double v, double* out);

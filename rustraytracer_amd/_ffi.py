@@ -52,7 +52,8 @@ class rt_mesh(C.Structure):
 
 class rt_texture(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("odd", C.c_uint32), ("even", C.c_uint32), ("reserved", C.c_uint32),
-                ("color", C.c_double * 3), ("frequency", C.c_double)]
+                ("color", C.c_double * 3), ("frequency", C.c_double),
+                ("rgbe", C.POINTER(C.c_uint8)), ("width", C.c_uint32), ("height", C.c_uint32)]
 
 
 class rt_material(C.Structure):
@@ -62,7 +63,8 @@ class rt_material(C.Structure):
 
 class rt_light(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("prim_index", C.c_uint32), ("two_sided", C.c_uint32),
-                ("reserved", C.c_uint32), ("color", C.c_double * 3), ("area", C.c_double)]
+                ("tex_index", C.c_uint32), ("xform_index", C.c_int32), ("reserved", C.c_uint32),
+                ("color", C.c_double * 3), ("area", C.c_double), ("world_radius", C.c_double)]
 
 
 class rt_scene_desc(C.Structure):

@@ -196,3 +196,9 @@ def sphere_roughness(aspect_ratio=1.0):
 
 def two_dragons(aspect_ratio=1.0, mesh_faces=0, mesh_path=None, variant=0):
     return Scene("two_dragons", aspect_ratio, mesh_faces, mesh_path, variant)
+
+
+def material_hdr(mat_num=0, aspect_ratio=1.0, mesh_faces=0, data_dir=None):
+    """scenes.rs:627-741 (row f4): environment-lit material test; mat_num 0 plastic / 1 metal / 2 mirror /
+    3 rough glass.  data_dir = the reference's data/material directory; missing files -> procedural stand-ins."""
+    return Scene("material_hdr", aspect_ratio, mesh_faces, data_dir, mat_num)

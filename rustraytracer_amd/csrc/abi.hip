@@ -18,6 +18,7 @@
 
 #include "bvh_build.h"
 #include "bvh_gpu.h"
+#include "env_dist.h"
 #include "device/kernels.hip"
 
 using namespace rtd;
@@ -92,8 +93,10 @@ struct rt_scene {
     std::vector<rt_xform> xforms;
     std::vector<rt_material> mats;
     std::vector<rt_texture> texs;
+    std::vector<std::vector<uint8_t>> hdr;  // texel copies of the RT_TEX_HDR textures (texs[i].rgbe points here)
     std::vector<rt_light> lights;
     bool committed = false;
+    bool full_shading = false;  // the scene needs the kernels compiled with the row-f4 features (rough glass, infinite light)
     // device
     std::vector<void*> allocs;
     DevScene dev{};
@@ -270,7 +273,16 @@ int rt_scene_set_materials(rt_scene* s, const rt_material* m, uint64_t count) {
 int rt_scene_set_textures(rt_scene* s, const rt_texture* t, uint64_t count) {
     SCENE_MUTABLE(s);
     if (count && !t) return fail(RT_ERR_INVALID_ARG, "textures is null");
+    for (uint64_t i = 0; i < count; i++)
+        if (t[i].kind == RT_TEX_HDR && (!t[i].rgbe || t[i].width == 0 || t[i].height == 0 || t[i].width > 32768 || t[i].height > 32768))
+            return fail(RT_ERR_INVALID_ARG, "texture %llu: HDR texels missing or bad size", (unsigned long long)i);
     s->texs.assign(t, t + count);
+    s->hdr.assign(count, {});
+    for (uint64_t i = 0; i < count; i++) {
+        if (t[i].kind != RT_TEX_HDR) continue;
+        s->hdr[i].assign(t[i].rgbe, t[i].rgbe + (size_t)t[i].width * t[i].height * 4);
+        s->texs[i].rgbe = s->hdr[i].data();
+    }
     return RT_OK;
 }
 int rt_scene_set_lights(rt_scene* s, const rt_light* l, uint64_t count) {
@@ -287,7 +299,7 @@ static int validate_scene(const rt_scene* s) {
         if (t.kind == RT_TEX_CHECKERED) {
             if (t.odd >= s->texs.size() || t.even >= s->texs.size())
                 return fail(RT_ERR_INVALID_ARG, "texture %zu: checker child out of range", i);
-        } else if (t.kind != RT_TEX_SOLID) {
+        } else if (t.kind != RT_TEX_SOLID && t.kind != RT_TEX_HDR) {
             return fail(RT_ERR_UNSUPPORTED, "texture %zu: kind %u is outside the hot-path scope", i, t.kind);
         }
     }
@@ -303,8 +315,6 @@ static int validate_scene(const rt_scene* s) {
             case RT_MAT_PLASTIC:
             case RT_MAT_GLASS:
                 if (!tex_ok(m.tex[0]) || !tex_ok(m.tex[1])) return fail(RT_ERR_INVALID_ARG, "material %zu: texture out of range", i);
-                if (m.kind == RT_MAT_GLASS && (m.f[0] != 0.0 || m.f[1] != 0.0))
-                    return fail(RT_ERR_UNSUPPORTED, "material %zu: rough glass (MicrofacetTransmission) is out of scope", i);
                 break;
             case RT_MAT_METAL:
                 if (!tex_ok(m.tex[0]) || !tex_ok(m.tex[1])) return fail(RT_ERR_INVALID_ARG, "material %zu: texture out of range", i);
@@ -332,9 +342,17 @@ static int validate_scene(const rt_scene* s) {
             if (p.xform_index >= (int32_t)s->xforms.size()) return fail(RT_ERR_INVALID_ARG, "primitive %zu: transform out of range", i);
         }
     }
+    int n_infinite = 0;
     for (size_t i = 0; i < s->lights.size(); i++) {
         const rt_light& l = s->lights[i];
-        if (l.kind != RT_LIGHT_DIFFUSE) return fail(RT_ERR_UNSUPPORTED, "light %zu: only Light::Diffuse is in scope", i);
+        if (l.kind == RT_LIGHT_INFINITE) {
+            if (++n_infinite > 1) return fail(RT_ERR_UNSUPPORTED, "light %zu: more than one infinite light", i);
+            if (l.tex_index >= s->texs.size() || s->texs[l.tex_index].kind != RT_TEX_HDR)
+                return fail(RT_ERR_INVALID_ARG, "light %zu: the environment map must be an RT_TEX_HDR texture", i);
+            if (l.xform_index >= (int32_t)s->xforms.size()) return fail(RT_ERR_INVALID_ARG, "light %zu: transform out of range", i);
+            continue;
+        }
+        if (l.kind != RT_LIGHT_DIFFUSE) return fail(RT_ERR_UNSUPPORTED, "light %zu: only Light::Diffuse and Light::Infinite are in scope", i);
         if (l.prim_index >= s->prims.size()) return fail(RT_ERR_INVALID_ARG, "light %zu: primitive out of range", i);
     }
     return RT_OK;
@@ -367,8 +385,39 @@ int rt_scene_commit_ex(rt_scene* s, uint32_t flags) {
     if ((rc = upload(s, dm.data(), dm.size(), &d.meshes)) != RT_OK) return rc;
     if ((rc = upload(s, s->xforms.data(), s->xforms.size(), &d.xforms)) != RT_OK) return rc;
     if ((rc = upload(s, s->mats.data(), s->mats.size(), &d.mats)) != RT_OK) return rc;
-    if ((rc = upload(s, s->texs.data(), s->texs.size(), &d.texs)) != RT_OK) return rc;
+    {   // textures: HDR texels go to HBM first, the records point at the device copies
+        std::vector<rt_texture> dtex = s->texs;
+        for (size_t i = 0; i < dtex.size(); i++) {
+            if (dtex[i].kind != RT_TEX_HDR) {
+                dtex[i].rgbe = nullptr;
+                continue;
+            }
+            const uint8_t* dp = nullptr;
+            if ((rc = upload(s, s->hdr[i].data(), s->hdr[i].size(), &dp)) != RT_OK) return rc;
+            dtex[i].rgbe = dp;
+        }
+        if ((rc = upload(s, dtex.data(), dtex.size(), &d.texs)) != RT_OK) return rc;
+    }
     if ((rc = upload(s, s->lights.data(), s->lights.size(), &d.lights)) != RT_OK) return rc;
+    d.env.light = -1;
+    s->full_shading = false;
+    for (const rt_material& m : s->mats)
+        if (m.kind == RT_MAT_GLASS && (m.f[0] != 0.0 || m.f[1] != 0.0)) s->full_shading = true;
+    for (size_t i = 0; i < s->lights.size(); i++) {
+        if (s->lights[i].kind != RT_LIGHT_INFINITE) continue;
+        // Light::make_infinite_light's Distribution2D (light.rs:608-638), rebuilt from the texels
+        EnvDist ed;
+        build_env_dist(s->texs[s->lights[i].tex_index], ed);
+        if ((rc = upload(s, ed.img.data(), ed.img.size(), &d.env.img)) != RT_OK) return rc;
+        if ((rc = upload(s, ed.cond_cdf.data(), ed.cond_cdf.size(), &d.env.cond_cdf)) != RT_OK) return rc;
+        if ((rc = upload(s, ed.marg_func.data(), ed.marg_func.size(), &d.env.marg_func)) != RT_OK) return rc;
+        if ((rc = upload(s, ed.marg_cdf.data(), ed.marg_cdf.size(), &d.env.marg_cdf)) != RT_OK) return rc;
+        d.env.marg_int = ed.marg_int;
+        d.env.nu = ed.nu;
+        d.env.nv = ed.nv;
+        d.env.light = (int32_t)i;
+        s->full_shading = true;
+    }
     uint64_t n_tri = 0;
     uint32_t depth = 0;
     const auto t0 = std::chrono::steady_clock::now();
@@ -545,7 +594,7 @@ static int run_lane(RenderJob& job, int lane_id) {
                 if (live <= c->tail_paths) {
                     // few paths left: one fused launch finishes them (k_tail) instead of ~2 launches per bounce
                     // that are each as slow as their single longest ray
-                    hipLaunchKernelGGL(k_tail, dim3((live + 255) / 256), dim3(256), 0, stream, job.s->dev, ln.st[0],
+                    hipLaunchKernelGGL(job.s->full_shading ? k_tail<true> : k_tail<false>, dim3((live + 255) / 256), dim3(256), 0, stream, job.s->dev, ln.st[0],
                                        ln.st[1], ln.ctl, (uint32_t)it, cfg->max_depth, c->lf[0], c->lf[1], c->lf[2],
                                        c->stats);
                     break;
@@ -584,7 +633,7 @@ static int run_lane(RenderJob& job, int lane_id) {
             ln.trace_ev.emplace_back(a, b);
         }
         ln.trace_launches++;
-        hipLaunchKernelGGL(k_shade, dim3(shade_blocks), dim3(256), 0, stream, job.s->dev, ln.st[it & 1],
+        hipLaunchKernelGGL(job.s->full_shading ? k_shade<true> : k_shade<false>, dim3(shade_blocks), dim3(256), 0, stream, job.s->dev, ln.st[it & 1],
                            ln.st[(it + 1) & 1], ln.ctl, (uint32_t)it, cfg->max_depth, ln.queue[(it + 1) & 1], c->lf[0],
                            c->lf[1], c->lf[2], c->stats);
     }

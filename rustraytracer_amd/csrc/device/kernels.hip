@@ -365,6 +365,7 @@ struct ShadeA {
     bool live, spec, will_shade;
 };
 
+template <bool FULL>
 RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool valid, uint32_t max_depth, ShadeA& a) {
     a.fl = valid ? in.flags[slot] : kDead;
     const uint32_t fl = a.fl;
@@ -378,13 +379,19 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool va
         if (fl & (kHasShadow | kHasProbe)) {
             const uint32_t light_idx = fl >> kLightShift;
             const rt_light& lt = sc.lights[light_idx];
+            const bool infinite = FULL && lt.kind == RT_LIGHT_INFINITE;
             D3 ld = black();
             if (fl & kHasShadow) {
-                if (in.sh_prim[slot] == (int32_t)lt.prim_index) ld = ld + ld3(in.ax, in.ay, in.az, slot);
+                // Visibility::unoccluded(infinite): an area light must be the closest hit, the environment needs a miss
+                const int32_t sh = in.sh_prim[slot];
+                if (infinite ? sh < 0 : sh == (int32_t)lt.prim_index) ld = ld + ld3(in.ax, in.ay, in.az, slot);
             }
             if (fl & kHasProbe) {
                 const int32_t pp = in.pr_prim[slot];
-                if (pp >= 0) {
+                if (infinite) {
+                    // integrator.rs:617-630: an escaped probe sees light.le(ray), already folded into q by shade_b
+                    if (pp < 0) ld = ld + ld3(in.qx, in.qy, in.qz, slot);
+                } else if (pp >= 0) {
                     const int32_t li = sc.prims[pp].light_index;
                     if (li >= 0 && (uint32_t)li == light_idx) {
                         const D3 pd = ld3(in.pdx, in.pdy, in.pdz, slot);
@@ -417,6 +424,9 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool va
             if (is_some) {
                 const int32_t li = sc.prims[a.rec.prim].light_index;
                 if (li >= 0) a.L = a.L + cmul(light_l(sc.lights[li], a.rec.n, -a.d), a.beta);
+            } else if (FULL && sc.env.light >= 0) {
+                // escaped: every light adds le(ray), black for all but the infinite one (light.rs:499-512)
+                a.L = a.L + cmul(infinite_le(sc, sc.lights[sc.env.light], a.d), a.beta);
             }
         }
     }
@@ -428,6 +438,7 @@ struct ShadeOut {
 };
 
 // Precondition: a.will_shade.  `os` = slot of `out` reserved for this vertex.
+template <bool FULL>
 RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& out, uint32_t slot, uint32_t os,
                      ShadeA& a) {
     const HitRec& rec = a.rec;
@@ -436,7 +447,7 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
     bool spec = a.spec;
     uint64_t rng = in.rng[slot];
     Bsdf bsdf;
-    compute_scattering(sc, rec, bsdf);
+    compute_scattering<FULL>(sc, rec, bsdf);
     bool has_sh = false, has_pr = false;
     uint32_t light_num = 0;
     // ---- uniform_sample_one_light / estimate_direct (integrator.rs:530-634)
@@ -447,31 +458,36 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
         const double ul0 = rng_next(rng), ul1 = rng_next(rng);
         const double us0 = rng_next(rng), us1 = rng_next(rng);
         const rt_light& lt = sc.lights[light_num];
-        const rt_primitive& lp = sc.prims[lt.prim_index];
+        const bool infinite = FULL && lt.kind == RT_LIGHT_INFINITE;
+        const rt_primitive& lp = sc.prims[infinite ? 0u : lt.prim_index];
         const uint32_t nsf = RT_BSDF_ALL - RT_BSDF_SPECULAR;
         const D3 ltcolor = d3(lt.color[0], lt.color[1], lt.color[2]);
         D3 sp, sn;
         double light_pdf;
-        sample_area(sc, lp, ul0, ul1, sp, sn, light_pdf);  // Primitive::sample (Q9)
-        const D3 wi_raw = sp - rec.p;
-        if (norm2(wi_raw) == 0.0) {
-            light_pdf = 0.0;
-        } else {
-            const D3 wn = normalize(wi_raw);
-            light_pdf = light_pdf * norm2(rec.p - sp) / absd(dot(sn, -wn));
-        }
         D3 wi, color;
-        if (light_pdf == 0.0 || norm2(rec.p - sp) == 0.0) {
-            light_pdf = 0.0;
-            wi = black();
-            color = ltcolor;
+        if (infinite) {
+            infinite_sample_li(sc, lt, rec.p, ul0, ul1, wi, light_pdf, color, sp);
         } else {
-            wi = normalize(sp - rec.p);
-            color = light_l(lt, sn, -wi);
+            sample_area(sc, lp, ul0, ul1, sp, sn, light_pdf);  // Primitive::sample (Q9)
+            const D3 wi_raw = sp - rec.p;
+            if (norm2(wi_raw) == 0.0) {
+                light_pdf = 0.0;
+            } else {
+                const D3 wn = normalize(wi_raw);
+                light_pdf = light_pdf * norm2(rec.p - sp) / absd(dot(sn, -wn));
+            }
+            if (light_pdf == 0.0 || norm2(rec.p - sp) == 0.0) {
+                light_pdf = 0.0;
+                wi = black();
+                color = ltcolor;
+            } else {
+                wi = normalize(sp - rec.p);
+                color = light_l(lt, sn, -wi);
+            }
         }
         if (light_pdf > 0.0 && !is_black(color)) {
-            const D3 f = bsdf_f(bsdf, rec.wo, wi, nsf) * absd(dot(wi, rec.sh_n));
-            const double scattering_pdf = bsdf_pdf(bsdf, rec.wo, wi, nsf);
+            const D3 f = bsdf_f<FULL>(bsdf, rec.wo, wi, nsf) * absd(dot(wi, rec.sh_n));
+            const double scattering_pdf = bsdf_pdf<FULL>(bsdf, rec.wo, wi, nsf);
             if (!is_black(f)) {
                 has_sh = true;
                 const double weight = power_heuristic(1, light_pdf, 1, scattering_pdf);
@@ -483,13 +499,13 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
             D3 f2, wi2;
             double spdf;
             uint32_t sampled;
-            bsdf_sample_f(bsdf, rec.wo, us0, us1, nsf, rng, f2, wi2, spdf, sampled);
+            bsdf_sample_f<FULL>(bsdf, rec.wo, us0, us1, nsf, rng, f2, wi2, spdf, sampled);
             f2 = f2 * absd(dot(wi2, rec.sh_n));
             if (!is_black(f2) && spdf > 0.0) {
                 double weight = 1.0;
                 bool go = true;
                 if ((sampled & RT_BSDF_SPECULAR) == 0) {
-                    const double lpdf = prim_pdf(sc, lp, rec.p, wi2);  // Light::pdf_li
+                    const double lpdf = infinite ? infinite_pdf_li(sc, lt, wi2) : prim_pdf(sc, lp, rec.p, wi2);  // Light::pdf_li
                     if (lpdf == 0.0)
                         go = false;
                     else
@@ -497,7 +513,9 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
                 }
                 if (go) {
                     has_pr = true;
-                    st3(out.qx, out.qy, out.qz, os, cmul(f2, ltcolor) * (weight / spdf));
+                    // the radiance an escaped probe would see is a function of its direction only: fold it in now
+                    const D3 pcol = infinite ? infinite_le(sc, lt, wi2) : ltcolor;
+                    st3(out.qx, out.qy, out.qz, os, is_black(pcol) ? black() : cmul(f2, pcol) * (weight / spdf));
                     st3(out.pdx, out.pdy, out.pdz, os, wi2);
                 }
             }
@@ -510,7 +528,7 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
     D3 f, wi;
     double pdf;
     uint32_t sflags;
-    bsdf_sample_f(bsdf, wo, u0, u1, RT_BSDF_ALL, rng, f, wi, pdf, sflags);
+    bsdf_sample_f<FULL>(bsdf, wo, u0, u1, RT_BSDF_ALL, rng, f, wi, pdf, sflags);
     bool cont = !(is_black(f) || pdf == 0.0);
     if (cont) {
         beta = cmul(beta, f) * (absd(dot(wi, rec.sh_n)) / pdf);
@@ -546,6 +564,7 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
     return r;
 }
 
+template <bool FULL>
 __global__ __launch_bounds__(256, 2) void k_shade(DevScene sc, PathState in, PathState out, Ctl* ctl, uint32_t it_abs,
                                                uint32_t max_depth, uint32_t* queue_out, double* lfx, double* lfy,
                                                double* lfz, DevStats* stats) {
@@ -558,7 +577,7 @@ __global__ __launch_bounds__(256, 2) void k_shade(DevScene sc, PathState in, Pat
     __shared__ uint32_t s_base[2];    // block's base in the next path list / ray queue
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     ShadeA a;
-    shade_a(sc, in, slot, slot < n_active, max_depth, a);
+    shade_a<FULL>(sc, in, slot, slot < n_active, max_depth, a);
     // a vertex that will be shaded gets its output slot now (dense, block-contiguous); if the path
     // then ends without pending light terms the slot is marked dead and skipped next bounce
     uint32_t os;
@@ -576,7 +595,7 @@ __global__ __launch_bounds__(256, 2) void k_shade(DevScene sc, PathState in, Pat
         os = off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     }
     ShadeOut r{false, false, false, false};
-    if (a.will_shade) r = shade_b(sc, in, out, slot, os, a);
+    if (a.will_shade) r = shade_b<FULL>(sc, in, out, slot, os, a);
     if (a.live && !r.keep) {  // retired: its radiance goes to the film staging slot of (pixel, sample)
         const uint32_t og = in.orig[slot];
         lfx[og] = a.L.x;
@@ -626,6 +645,7 @@ __global__ __launch_bounds__(256, 2) void k_shade(DevScene sc, PathState in, Pat
 // finishes those paths in ONE launch: each lane traces its own pending rays (shadow, probe, extension)
 // with the same closest_hit and shades with the same shade_a / shade_b, ping-ponging its slot between
 // the two state buffers, until its path retires.  Same arithmetic, same counters, no queues.
+template <bool FULL>
 __global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathState buf1, const Ctl* ctl,
                                              uint32_t it_abs, uint32_t max_depth, double* lfx, double* lfy,
                                              double* lfz, DevStats* stats) {
@@ -656,10 +676,10 @@ __global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathS
         if (!(fl & kFoldOnly))
             in.hit_prim[slot] = closest_hit<false>(sc, o, ld3(in.dx, in.dy, in.dz, slot), kSmall, kInf, t, ts, &tc);
         ShadeA a;
-        shade_a(sc, in, slot, true, max_depth, a);
+        shade_a<FULL>(sc, in, slot, true, max_depth, a);
         ShadeOut r{false, false, false, false};
         if (a.will_shade) {
-            r = shade_b(sc, in, out, slot, slot, a);
+            r = shade_b<FULL>(sc, in, out, slot, slot, a);
             n_v++;
         }
         n_r1 += r.emit_ext ? 1u : 0u;

@@ -33,6 +33,21 @@ struct DevMesh {
     const uint32_t* ind;
 };
 
+// Light::Infinite (next-row f4): the Distribution2D of make_infinite_light (light.rs:608-638,
+// distribution.rs:93-150), flattened.  Row v of the reference's conditional distributions is the window
+// img[v .. v + nu) of the (nu x nv) luminance image (distribution.rs:118 slices `f[v..(v + nu)]`), so the
+// rows share `img`; their cdfs are stored one after the other, nu + 1 entries each.
+struct DevEnv {
+    const double* img;        // nu * nv, luminance * sin(theta)
+    const double* cond_cdf;   // nv rows of nu + 1
+    const double* marg_func;  // nv: func_int of row v
+    const double* marg_cdf;   // nv + 1
+    double marg_int;          // p_marginal.func_int
+    uint32_t nu, nv;
+    int32_t light;            // index of the infinite light, -1: none
+    uint32_t pad;
+};
+
 struct DevScene {
     const DevNode* nodes;
     const uint32_t* leaf_prim;  // leaf order -> prim index | kLeafOther
@@ -44,6 +59,7 @@ struct DevScene {
     const rt_texture* texs;
     const rt_light* lights;
     uint32_t n_prims, n_lights, n_nodes, mesh_has_uv;  // mesh_has_uv: any mesh carries uvs
+    DevEnv env;
 };
 
 // ----------------------------------------------------------------- path state

@@ -10,6 +10,11 @@
 //   TrowbridgeReitz d/lambda/g/pdf/sample src/microfacet.rs:53-68, 109-172, 240-282, 442-512
 //   Primitive::{area,sample_area,pdf}     src/primitive.rs:339-359, 438-539 (Q8, Q9)
 //   Light::l                              src/light.rs:475-496           (Q7)
+// next-row f4:
+//   Texture::Hdr arm of get_value         src/material.rs:570-587
+//   Bxdf::MicrofacetTransmission          src/bxdf.rs:393-441, 608-638, 742-763
+//   Distribution1D/2D sampling and pdf    src/distribution.rs:64-78, 133-166
+//   Light::Infinite sample_li/pdf_li/le   src/light.rs:204-245, 285-294, 499-512
 #pragma once
 #include "geom.h"
 
@@ -50,6 +55,23 @@ RTD D3 rand_cosine_dir(double r1, double r2) {
 // material.rs:542-565: Checkered follows even/odd ids (bounded depth, like the oracle)
 // noinline + rolled loop: inlining this (two dm_sin per checker level, eight levels, a dozen call
 // sites in compute_scattering) multiplied k_shade's code size several times over the I-cache.
+RTD uint32_t sat_u32(double x) {  // Rust `f64 as u32`: saturating, NaN -> 0
+    if (!(x > 0.0)) return 0u;
+    if (x >= 4294967295.0) return 4294967295u;
+    return (uint32_t)x;
+}
+// material.rs:570-587; texels are image::hdr::to_rgbe8(data[i]) (rt_abi.h)
+RTD D3 hdr_value(const rt_texture& t, double u, double v) {
+    const uint32_t width = t.width, height = t.height;
+    uint32_t x = sat_u32(__builtin_round((1.0 - u) * (double)width));
+    uint32_t y = sat_u32(__builtin_round(v * (double)height));
+    x = x % width;
+    y = y % height;
+    const uint32_t q = reinterpret_cast<const uint32_t*>(t.rgbe)[(size_t)y * width + x];  // c0 | c1<<8 | c2<<16 | e<<24
+    const double sc = dm_from_bits((uint64_t)(1023 + (int)(q >> 24) - 128) << 52);       // 2^(e-128), exact
+    return d3(((double)(q & 0xffu) + 0.5) * sc / 256.0, ((double)((q >> 8) & 0xffu) + 0.5) * sc / 256.0,
+              ((double)((q >> 16) & 0xffu) + 0.5) * sc / 256.0);
+}
 RTDN D3 texture_value(const DevScene& sc, uint32_t index, double u, double v) {
 #pragma unroll 1
     for (int depth = 0; depth < 8; depth++) {
@@ -59,6 +81,7 @@ RTDN D3 texture_value(const DevScene& sc, uint32_t index, double u, double v) {
         index = (mult < 0.0) ? t.even : t.odd;
     }
     const rt_texture& t = sc.texs[index];
+    if (t.kind == RT_TEX_HDR) return hdr_value(t, u, v);
     return d3(t.color[0], t.color[1], t.color[2]);
 }
 
@@ -102,7 +125,7 @@ RTD D3 fr_conductor(double cos_theta_i, D3 eta, D3 eta_k) {
     return (rp + rs) * 0.5;
 }
 
-enum LobeKind { LOBE_LAMBERT = 0, LOBE_MICROFACET = 1, LOBE_FRESNEL_SPECULAR = 2, LOBE_SPECULAR_REFL = 3 };
+enum LobeKind { LOBE_LAMBERT = 0, LOBE_MICROFACET = 1, LOBE_FRESNEL_SPECULAR = 2, LOBE_SPECULAR_REFL = 3, LOBE_MICRO_TRANS = 4 };
 enum FresnelKind { FR_DIELECTRIC = 0, FR_CONDUCTOR = 1, FR_NOOP = 2 };
 
 struct Lobe {
@@ -112,7 +135,7 @@ struct Lobe {
     D3 t;      // FresnelSpecular t; FresnelConductor eta
     D3 k;      // FresnelConductor k
     int fresnel;
-    double p0, p1;  // dielectric (eta_i, eta_t) | FresnelSpecular (eta_a, eta_b)
+    double p0, p1;  // dielectric (eta_i, eta_t) | FresnelSpecular, MicrofacetTransmission (eta_a, eta_b)
     double alpha_x, alpha_y;
 };
 struct Bsdf {
@@ -227,6 +250,9 @@ RTD double tr_roughness_to_alpha(double roughness) {  // microfacet.rs:442-446
 
 RTD bool matches_flags(uint32_t flag, uint32_t other) { return (flag & other) == flag; }
 
+// FULL: the scene uses the next-row f4 features (MicrofacetTransmission lobes, an infinite light); scenes that
+// do not run the kernels compiled without them (k_shade<false>), which keeps their register budget.
+template <bool FULL>
 RTD D3 bxdf_f(const Lobe& l, D3 wo, D3 wi) {
     if (l.kind == LOBE_LAMBERT) return l.color * kInvPi;
     if (l.kind == LOBE_MICROFACET) {
@@ -239,8 +265,25 @@ RTD D3 bxdf_f(const Lobe& l, D3 wo, D3 wi) {
         D3 comp1 = l.color * tr_d(l.alpha_x, l.alpha_y, wh) * tr_g(l.alpha_x, l.alpha_y, wo, wi);
         return cmul(comp1, f * (1.0 / (4.0 * cos_i * cos_o)));
     }
+    if (FULL && l.kind == LOBE_MICRO_TRANS) {  // bxdf.rs:393-441 (mode == RADIANCE); eta_a = p0, eta_b = p1
+        if (same_hemisphere(wo, wi)) return black();
+        const double cos_theta_o = wo.z, cos_theta_i = wi.z;
+        if (cos_theta_i == 0.0 || cos_theta_o == 0.0) return black();
+        const double eta = wo.z > 0.0 ? l.p1 / l.p0 : l.p0 / l.p1;
+        D3 wh = normalize(wo + wi * eta);
+        if (wh.z < 0.0) wh = -wh;
+        if (dot(wo, wh) * dot(wi, wh) > 0.0) return black();
+        const D3 f = fresnel_evaluate(l, dot(wo, wh));
+        const double sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
+        const double factor = 1.0 / eta;
+        const D3 c = cmul(white() - f, l.color);
+        return c * absd(tr_d(l.alpha_x, l.alpha_y, wh) * tr_g(l.alpha_x, l.alpha_y, wo, wi) * eta * eta *
+                        absd(dot(wi, wh)) * absd(dot(wo, wh)) * factor * factor /
+                        (cos_theta_i * cos_theta_o * sqrt_denom * sqrt_denom));
+    }
     return black();
 }
+template <bool FULL>
 RTD double bxdf_pdf(const Lobe& l, D3 wo, D3 wi) {
     if (l.kind == LOBE_LAMBERT || l.kind == LOBE_SPECULAR_REFL)
         return same_hemisphere(wo, wi) ? absd(wi.z) * kInvPi : 0.0;
@@ -249,9 +292,19 @@ RTD double bxdf_pdf(const Lobe& l, D3 wo, D3 wi) {
         D3 wh = normalize(wo + wi);
         return tr_pdf(l.alpha_x, l.alpha_y, wo, wh) / (4.0 * dot(wo, wh));
     }
+    if (FULL && l.kind == LOBE_MICRO_TRANS) {  // bxdf.rs:742-763
+        if (same_hemisphere(wo, wi)) return 0.0;
+        const double eta = wo.z > 0.0 ? l.p1 / l.p0 : l.p0 / l.p1;
+        const D3 wh = normalize(wo + wi * eta);
+        if (dot(wo, wh) * dot(wi, wh) > 0.0) return 0.0;
+        const double sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
+        const double dwh_dwi = absd(eta * eta * dot(wi, wh)) / (sqrt_denom * sqrt_denom);
+        return tr_pdf(l.alpha_x, l.alpha_y, wo, wh) * dwh_dwi;
+    }
     return 0.0;
 }
 // `rng` supplies default_sample_f's two entropy draws (bxdf.rs:815-827)
+template <bool FULL>
 RTD void bxdf_sample_f(const Lobe& l, D3 wo, double u0, double u1, uint64_t& rng, D3& f, D3& wi, double& pdf) {
     f = black();
     wi = black();
@@ -261,8 +314,8 @@ RTD void bxdf_sample_f(const Lobe& l, D3 wo, double u0, double u1, uint64_t& rng
         double r2 = rng_next(rng);
         wi = rand_cosine_dir(r1, r2);
         if (wo.z < 0.0) wi.z *= -1.0;
-        pdf = bxdf_pdf(l, wo, wi);
-        f = bxdf_f(l, wo, wi);
+        pdf = bxdf_pdf<FULL>(l, wo, wi);
+        f = bxdf_f<FULL>(l, wo, wi);
     } else if (l.kind == LOBE_MICROFACET) {
         if (wo.z == 0.0) return;
         D3 wh = tr_sample_wh(l.alpha_x, l.alpha_y, wo, u0, u1);
@@ -270,7 +323,7 @@ RTD void bxdf_sample_f(const Lobe& l, D3 wo, double u0, double u1, uint64_t& rng
         if (!same_hemisphere(wo, w2)) return;
         wi = w2;
         pdf = tr_pdf(l.alpha_x, l.alpha_y, wo, wh) / (4.0 * dot(wo, wh));
-        f = bxdf_f(l, wo, wi);
+        f = bxdf_f<FULL>(l, wo, wi);
     } else if (l.kind == LOBE_FRESNEL_SPECULAR) {  // Q15
         double fr = fr_dielectric(wo.z / norm(wo), l.p0, l.p1);
         if (u0 < fr) {
@@ -290,6 +343,16 @@ RTD void bxdf_sample_f(const Lobe& l, D3 wo, double u0, double u1, uint64_t& rng
             wi = dirv;
             pdf = 1.0 - fr;
         }
+    } else if (FULL && l.kind == LOBE_MICRO_TRANS) {  // bxdf.rs:608-638
+        if (wo.z == 0.0) return;
+        const D3 wh = tr_sample_wh(l.alpha_x, l.alpha_y, wo, u0, u1);
+        if (dot(wo, wh) < 0.0) return;
+        const double eta = wo.z > 0.0 ? l.p0 / l.p1 : l.p1 / l.p0;
+        D3 t;
+        if (!refract(wo, wh, eta, t)) return;
+        wi = t;
+        pdf = bxdf_pdf<FULL>(l, wo, wi);
+        f = bxdf_f<FULL>(l, wo, wi);
     } else {  // LOBE_SPECULAR_REFL, bxdf.rs:543-552
         wi = d3(-wo.x, -wo.y, wo.z);
         f = cmul(l.color, fresnel_evaluate(l, wi.z));
@@ -317,6 +380,7 @@ RTD int num_components(const Bsdf& b, uint32_t flags) {
     if (b.n > 1 && matches_flags(b.lobes[1].type, flags)) c++;
     return c;
 }
+template <bool FULL>
 RTD D3 bsdf_f(const Bsdf& b, D3 wow, D3 wiw, uint32_t flags) {  // bsdf.rs:83-98 (Q10)
     D3 wi = w2l(b, wiw), wo = w2l(b, wow);
     bool refl = dot(wiw, b.ng) * dot(wow, b.ng) > 0.0;
@@ -327,10 +391,11 @@ RTD D3 bsdf_f(const Bsdf& b, D3 wow, D3 wiw, uint32_t flags) {  // bsdf.rs:83-98
         const Lobe& l = b.lobes[i];
         if ((matches_flags(l.type, flags) && (refl && (l.type & RT_BSDF_REFLECTION) > 0)) ||
             (!refl && (l.type & RT_BSDF_TRANSMISSION) > 0))
-            f = f + bxdf_f(l, wo, wi);
+            f = f + bxdf_f<FULL>(l, wo, wi);
     }
     return f;
 }
+template <bool FULL>
 RTD double bsdf_pdf(const Bsdf& b, D3 wow, D3 wiw, uint32_t flags) {  // bsdf.rs:166-189 (Q11)
     int nc = num_components(b, RT_BSDF_ALL);
     if (nc == 0) return 0.0;
@@ -343,11 +408,12 @@ RTD double bsdf_pdf(const Bsdf& b, D3 wow, D3 wiw, uint32_t flags) {  // bsdf.rs
         if (i >= nc) break;
         if (matches_flags(b.lobes[i].type, flags)) {
             matching++;
-            pdf += bxdf_pdf(b.lobes[i], wo, wi);
+            pdf += bxdf_pdf<FULL>(b.lobes[i], wo, wi);
         }
     }
     return matching > 0 ? pdf : 0.0;
 }
+template <bool FULL>
 RTD void bsdf_sample_f(const Bsdf& b, D3 wow, double u0, double u1, uint32_t type, uint64_t& rng, D3& color, D3& wiw,
                        double& pdf, uint32_t& sampled) {  // bsdf.rs:102-164
     int matching = num_components(b, type);
@@ -375,14 +441,14 @@ RTD void bsdf_sample_f(const Bsdf& b, D3 wow, double u0, double u1, uint32_t typ
     if (wo.z == 0.0) return;
     D3 f, wi;
     double p;
-    bxdf_sample_f(l, wo, u0, u1, rng, f, wi, p);
+    bxdf_sample_f<FULL>(l, wo, u0, u1, rng, f, wi, p);
     if (p == 0.0) return;
     D3 wiw_ = l2w(b, wi);
     if ((l.type & RT_BSDF_SPECULAR) == 0 && matching > 1) {
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             if (i >= b.n) break;
-            if (i != used && matches_flags(b.lobes[i].type, type)) p += bxdf_pdf(b.lobes[i], wo, wi);
+            if (i != used && matches_flags(b.lobes[i].type, type)) p += bxdf_pdf<FULL>(b.lobes[i], wo, wi);
         }
     }
     if (matching > 1) p = p / (double)matching;
@@ -395,7 +461,7 @@ RTD void bsdf_sample_f(const Bsdf& b, D3 wow, double u0, double u1, uint32_t typ
             const Lobe& li = b.lobes[i];
             if (matches_flags(li.type, type) && ((refl && (li.type & RT_BSDF_REFLECTION) > 0) ||
                                                  (!refl && (li.type & RT_BSDF_TRANSMISSION) > 0)))
-                f = f + bxdf_f(li, wo, wi);
+                f = f + bxdf_f<FULL>(li, wo, wi);
         }
     }
     color = f;
@@ -441,6 +507,7 @@ RTD Lobe make_microfacet(D3 c, double ax, double ay) {  // + microfacet.rs:340-3
 }
 
 // material.rs:80-244 with mode = RADIANCE, allow_lobes = true
+template <bool FULL>
 RTD void compute_scattering(const DevScene& sc, const HitRec& h, Bsdf& b) {
     const rt_material& m = sc.mats[h.mat];
     b.n = 0;
@@ -482,15 +549,44 @@ RTD void compute_scattering(const DevScene& sc, const HitRec& h, Bsdf& b) {
         D3 t = texture_value(sc, m.tex[1], h.u, h.v);
         bsdf_init(b, h);
         if (!(is_black(r) && is_black(t))) {
-            Lobe l = lobe_zero();
-            l.kind = LOBE_FRESNEL_SPECULAR;
-            l.type = RT_BSDF_TRANSMISSION | RT_BSDF_REFLECTION | RT_BSDF_SPECULAR;
-            l.color = r;
-            l.t = t;
-            l.p0 = m.f[2];
-            l.p1 = 1.0;
-            b.lobes[0] = l;
-            b.n = 1;
+            double urough = m.f[0], vrough = m.f[1];
+            if (!FULL || (urough == 0.0 && vrough == 0.0)) {  // is_specular && allow_lobes
+                Lobe l = lobe_zero();
+                l.kind = LOBE_FRESNEL_SPECULAR;
+                l.type = RT_BSDF_TRANSMISSION | RT_BSDF_REFLECTION | RT_BSDF_SPECULAR;
+                l.color = r;
+                l.t = t;
+                l.p0 = m.f[2];
+                l.p1 = 1.0;
+                b.lobes[0] = l;
+                b.n = 1;
+            } else {  // material.rs:161-189: MicrofacetReflection + MicrofacetTransmission
+                if (m.remap_roughness) {
+                    urough = tr_roughness_to_alpha(urough);
+                    vrough = tr_roughness_to_alpha(vrough);
+                }
+                if (!is_black(r)) {
+                    Lobe l = make_microfacet(r, urough, vrough);
+                    l.fresnel = FR_DIELECTRIC;
+                    l.p0 = m.f[2];
+                    l.p1 = 1.0;
+                    b.lobes[0] = l;
+                    b.n = 1;
+                }
+                if (!is_black(t)) {
+                    Lobe l = make_microfacet(t, urough, vrough);
+                    l.kind = LOBE_MICRO_TRANS;
+                    l.type = RT_BSDF_TRANSMISSION | RT_BSDF_GLOSSY;
+                    l.fresnel = FR_DIELECTRIC;
+                    l.p0 = m.f[2];
+                    l.p1 = 1.0;
+                    if (b.n == 0)
+                        b.lobes[0] = l;
+                    else
+                        b.lobes[1] = l;
+                    b.n++;
+                }
+            }
         }
     } else if (m.kind == RT_MAT_METAL) {
         bsdf_init(b, h);
@@ -580,6 +676,96 @@ RTD double prim_pdf(const DevScene& sc, const rt_primitive& pr, D3 rec_p, D3 dir
     D3 dist = rec_p - nh.p;
     return norm2(dist) / (prim_area(sc, pr) * absd(dot(nh.n, -dir)));
 }
+// ------------------------------------------------------ Light::Infinite
+// distribution.rs:152-166 find_interval over cdf[0..size) with pred = cdf[i] <= u
+RTD uint32_t find_interval(const double* __restrict__ cdf, uint32_t size, double u) {
+    uint32_t first = 0, len = size;
+    while (len > 0) {
+        const uint32_t half = len >> 1, middle = first + half;
+        if (cdf[middle] <= u) {
+            first = middle + 1;
+            len = len - half - 1;
+        } else {
+            len = half;
+        }
+    }
+    // clamp((first - 1) as f64, 0, size - 2) as usize; first == 0 (u < 0 / NaN) wraps to usize::MAX in release
+    const double x = first == 0 ? 18446744073709551615.0 : (double)(first - 1);
+    return sat_u32(clampd(x, 0.0, (double)(size - 2)));
+}
+// distribution.rs:64-78 sample_continuous
+RTD void dist1d_sample(const double* __restrict__ func, const double* __restrict__ cdf, uint32_t n, double func_int,
+                       double u, double& x, double& pdf, uint32_t& offset) {
+    offset = find_interval(cdf, n + 1, u);
+    double du = u - cdf[offset];
+    if (cdf[offset + 1] - cdf[offset] > 0.0) du = du / (cdf[offset + 1] - cdf[offset]);
+    pdf = func_int > 0.0 ? func[offset] / func_int : 0.0;
+    x = ((double)offset + du) / (double)n;
+}
+RTD void dist2d_sample(const DevEnv& e, double u0, double u1, double& x0, double& x1, double& pdf) {  // :133-137
+    double pdf1, pdf0;
+    uint32_t v, off;
+    dist1d_sample(e.marg_func, e.marg_cdf, e.nv, e.marg_int, u1, x1, pdf1, v);
+    dist1d_sample(e.img + v, e.cond_cdf + (size_t)v * (e.nu + 1), e.nu, e.marg_func[v], u0, x0, pdf0, off);
+    pdf = pdf1 * pdf0;
+}
+RTD double dist2d_pdf(const DevEnv& e, double p0, double p1) {  // distribution.rs:139-145
+    uint32_t iu = sat_u32(p0 * (double)e.nu);
+    if (iu > e.nu - 1) iu = e.nu - 1;
+    uint32_t iv = sat_u32(p1 * (double)e.nv);
+    if (iv > e.nv - 1) iv = e.nv - 1;
+    return e.img[(size_t)iv + iu] / e.marg_int;
+}
+RTD double spherical_theta(D3 v) { return dm_acos(clampd(v.y, -1.0, 1.0)); }  // util.rs:153-155
+RTD double spherical_phi(D3 v) {                                              // util.rs:160-167
+    const double p = dm_atan2(v.z, v.x);
+    return p < 0.0 ? p + 2.0 * kPi : p;
+}
+RTD D3 light_to_world(const DevScene& sc, const rt_light& lt, D3 v) {
+    return lt.xform_index >= 0 ? xf_vector(sc.xforms[lt.xform_index].fwd, v) : v;
+}
+RTD D3 light_to_obj(const DevScene& sc, const rt_light& lt, D3 v) {
+    return lt.xform_index >= 0 ? xf_vector(sc.xforms[lt.xform_index].inv, v) : v;
+}
+// light.rs:499-512 Light::le of the infinite light
+RTDN D3 infinite_le(const DevScene& sc, const rt_light& lt, D3 dir) {
+    const D3 w = normalize(light_to_obj(sc, lt, dir));
+    const double kInv2Pi = 1.0 / (2.0 * kPi);
+    return texture_value(sc, lt.tex_index, spherical_phi(w) * kInv2Pi, spherical_theta(w) * kInvPi);
+}
+// light.rs:285-294 pdf_li (through to_world, as the reference does)
+RTDN double infinite_pdf_li(const DevScene& sc, const rt_light& lt, D3 wi) {
+    const D3 w = light_to_world(sc, lt, wi);
+    const double theta = spherical_theta(w), phi = spherical_phi(w);
+    const double sin_theta = dm_sin(theta);
+    if (sin_theta == 0.0) return 0.0;
+    const double kInv2Pi = 1.0 / (2.0 * kPi);
+    return dist2d_pdf(sc.env, phi * kInv2Pi, theta * kInvPi) / (2.0 * kPi * kPi * sin_theta);
+}
+// light.rs:204-245 sample_li: direction (normalised), pdf, radiance and the far end of the Visibility segment
+RTDN void infinite_sample_li(const DevScene& sc, const rt_light& lt, D3 p, double u0, double u1, D3& wi, double& pdf,
+                             D3& color, D3& far_end) {
+    double uv0, uv1, map_pdf;
+    dist2d_sample(sc.env, u0, u1, uv0, uv1, map_pdf);
+    if (map_pdf == 0.0) {
+        wi = black();
+        pdf = 0.0;
+        color = black();
+        far_end = black();
+        return;
+    }
+    const double theta = uv1 * kPi, phi = uv0 * 2.0 * kPi;
+    const double cos_theta = dm_cos(theta), sin_theta = dm_sin(theta);
+    const double cos_phi = dm_cos(phi), sin_phi = dm_sin(phi);
+    const D3 v = d3(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta);
+    const D3 wiv = light_to_world(sc, lt, v);
+    pdf = map_pdf / (2.0 * kPi * kPi * sin_theta);
+    if (sin_theta == 0.0) pdf = 0.0;
+    far_end = p + wiv * (2.0 * lt.world_radius);
+    color = texture_value(sc, lt.tex_index, uv0, uv1);
+    wi = normalize(wiv);
+}
+
 RTD double power_heuristic(int nf, double f_pdf, int ng, double g_pdf) {  // integrator.rs:655-659
     double f = (double)nf * f_pdf, g = (double)ng * g_pdf;
     return (f * f) / (f * f + g * g);

@@ -4,6 +4,7 @@
 #include "rr_host.hpp"
 
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 
 #include "../../../include/rt_detmath.h"
@@ -71,6 +72,11 @@ Mat4 Mat4::operator*(const Mat4& o) const {
             r.m[i * 4 + j] = s;
         }
     return r;
+}
+Mat4 Mat4::from_rows(const double (&r)[16]) {
+    Mat4 o;
+    for (int i = 0; i < 16; i++) o.m[i] = r[i];
+    return o;
 }
 Mat4 Mat4::affine_inverse() const {
     // inverse of [A t; 0 1] = [A^-1  -A^-1 t; 0 1], A^-1 by cofactors
@@ -267,6 +273,146 @@ rt_texture Texture::new_checkered(uint32_t even, uint32_t odd, double frequency)
     t.frequency = frequency;
     return t;
 }
+// ---- Texture::Hdr (row f4)
+// image 0.23.12 (Cargo.lock; not vendored) image::hdr, restated from its published source:
+//   Rgbe8Pixel::to_hdr:  e == 0 -> 0, else exp2(e - (128 + 8)) * c[i]           (f32)
+//   to_rgbe8:  mx = max(r, g, b); mx <= 0 -> (0,0,0,0); else exp = floor(log2(mx)) + 1,
+//              c[i] = trunc(v[i] / 2^exp * 256) as u8, e = (exp + 128) as u8    (f32)
+void Texture::rgbe_to_hdr(const uint8_t* q, float* rgb) {
+    if (q[3] == 0) {
+        rgb[0] = rgb[1] = rgb[2] = 0.0f;
+        return;
+    }
+    const float ex = std::exp2((float)q[3] - (128.0f + 8.0f));
+    for (int i = 0; i < 3; i++) rgb[i] = ex * (float)q[i];
+}
+static uint8_t sat_u8(float x) {  // Rust `f32 as u8`: saturating, NaN -> 0
+    if (!(x > 0.0f)) return 0;
+    if (x >= 255.0f) return 255;
+    return (uint8_t)x;
+}
+void Texture::hdr_to_rgbe8(const float* rgb, uint8_t* q) {
+    const float mx = std::fmax(rgb[0], std::fmax(rgb[1], rgb[2]));
+    if (mx <= 0.0f) {
+        q[0] = q[1] = q[2] = q[3] = 0;
+        return;
+    }
+    const int ex = (int)std::floor(std::log2(mx)) + 1;
+    const float mul = std::ldexp(1.0f, ex);
+    for (int i = 0; i < 3; i++) q[i] = sat_u8(std::trunc(rgb[i] / mul * 256.0f));
+    q[3] = (uint8_t)(ex + 128);
+}
+static rt_texture hdr_texture(Objects& objs, std::shared_ptr<std::vector<uint8_t>> texels, uint32_t w, uint32_t h) {
+    rt_texture t;
+    std::memset(&t, 0, sizeof(t));
+    t.kind = RT_TEX_HDR;
+    t.width = w;
+    t.height = h;
+    t.rgbe = texels->data();
+    objs.hdr_store.push_back(std::move(texels));
+    return t;
+}
+// Radiance RGBE reader: header lines up to the blank line, "-Y h +X w", then scanlines, new-style RLE
+// (2 2 hi lo, then the four channels run-length coded) or flat RGBE quadruples.
+bool Texture::new_hdr(Objects& objs, const std::string& path, rt_texture& out, std::string& err) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) {
+        err = "Unable to open file " + path;  // material.rs:632
+        return false;
+    }
+    std::vector<uint8_t> buf;
+    {
+        uint8_t chunk[65536];
+        size_t got;
+        while ((got = std::fread(chunk, 1, sizeof(chunk), f)) > 0) buf.insert(buf.end(), chunk, chunk + got);
+        std::fclose(f);
+    }
+    size_t pos = 0;
+    auto line = [&](std::string& l) {
+        l.clear();
+        if (pos >= buf.size()) return false;
+        while (pos < buf.size() && buf[pos] != '\n') l.push_back((char)buf[pos++]);
+        pos++;
+        return true;
+    };
+    std::string l;
+    if (!line(l) || (l.rfind("#?RADIANCE", 0) != 0 && l.rfind("#?RGBE", 0) != 0)) {
+        err = "Failure decoding hdr " + path;
+        return false;
+    }
+    while (line(l) && !l.empty()) {}
+    long w = 0, h = 0;
+    if (!line(l) || std::sscanf(l.c_str(), "-Y %ld +X %ld", &h, &w) != 2 || w <= 0 || h <= 0 || w > 65535 || h > 65535) {
+        err = "Failure decoding hdr " + path + " (only -Y h +X w is supported)";
+        return false;
+    }
+    auto texels = std::make_shared<std::vector<uint8_t>>((size_t)w * h * 4);
+    std::vector<uint8_t> row((size_t)w * 4);
+    for (long y = 0; y < h; y++) {
+        bool ok = true;
+        if (pos + 4 <= buf.size() && buf[pos] == 2 && buf[pos + 1] == 2 && ((buf[pos + 2] << 8) | buf[pos + 3]) == w &&
+            w >= 8 && w < 32768) {
+            pos += 4;
+            for (int ch = 0; ch < 4 && ok; ch++) {
+                long x = 0;
+                while (x < w && ok) {
+                    if (pos >= buf.size()) { ok = false; break; }
+                    uint8_t cnt = buf[pos++];
+                    if (cnt > 128) {
+                        cnt -= 128;
+                        if (pos >= buf.size() || x + cnt > w) { ok = false; break; }
+                        const uint8_t v = buf[pos++];
+                        for (int k = 0; k < cnt; k++) row[(size_t)(x++) * 4 + ch] = v;
+                    } else {
+                        if (cnt == 0 || pos + cnt > buf.size() || x + cnt > w) { ok = false; break; }
+                        for (int k = 0; k < cnt; k++) row[(size_t)(x++) * 4 + ch] = buf[pos++];
+                    }
+                }
+            }
+        } else {
+            if (pos + (size_t)w * 4 > buf.size()) ok = false;
+            else {
+                std::memcpy(row.data(), &buf[pos], (size_t)w * 4);
+                pos += (size_t)w * 4;
+            }
+        }
+        if (!ok) {
+            err = "Failure to decode data from hdr " + path;
+            return false;
+        }
+        for (long x = 0; x < w; x++) {  // read_image_hdr -> Rgb<f32>, then get_value's to_rgbe8
+            float rgb[3];
+            rgbe_to_hdr(&row[(size_t)x * 4], rgb);
+            hdr_to_rgbe8(rgb, &(*texels)[((size_t)y * w + x) * 4]);
+        }
+    }
+    out = hdr_texture(objs, std::move(texels), (uint32_t)w, (uint32_t)h);
+    return true;
+}
+rt_texture Texture::new_hdr_procedural(Objects& objs, uint32_t w, uint32_t h) {
+    auto texels = std::make_shared<std::vector<uint8_t>>((size_t)w * h * 4);
+    const double pi = 3.141592653589793;
+    for (uint32_t y = 0; y < h; y++)
+        for (uint32_t x = 0; x < w; x++) {
+            // lat-long: v = 0 is the zenith.  Blue-ish sky brightening to the horizon, a warm ground, one sun.
+            const double v = (y + 0.5) / h, u = (x + 0.5) / w;
+            const double el = (0.5 - v) * pi;  // elevation
+            double r, g, b;
+            if (el > 0.0) {
+                const double t = std::pow(1.0 - std::sin(el), 3.0);
+                r = 0.25 + 0.9 * t; g = 0.45 + 0.8 * t; b = 0.9 + 0.5 * t;
+            } else {
+                const double t = std::pow(1.0 + std::sin(el), 4.0);
+                r = 0.22 + 0.5 * t; g = 0.18 + 0.45 * t; b = 0.12 + 0.4 * t;
+            }
+            const double du = (u - 0.3) * 2.0 * pi * std::cos(el), dv = el - 0.7;  // sun at azimuth 0.3, elevation 0.7 rad
+            const double d2 = du * du + dv * dv;
+            const double sun = 400.0 * std::exp(-d2 / (2.0 * 0.03 * 0.03)) + 6.0 * std::exp(-d2 / (2.0 * 0.25 * 0.25));
+            const float rgb[3] = {(float)(r + sun), (float)(g + 0.9 * sun), (float)(b + 0.7 * sun)};
+            hdr_to_rgbe8(rgb, &(*texels)[((size_t)y * w + x) * 4]);
+        }
+    return hdr_texture(objs, std::move(texels), w, h);
+}
 static rt_material mat_blank(uint32_t kind) {
     rt_material m;
     std::memset(&m, 0, sizeof(m));
@@ -331,6 +477,26 @@ rt_light Light::make_diffuse_light(const Objects& objs, uint32_t prim_index, Vec
     l.two_sided = two_sided ? 1 : 0;
     l.color[0] = color.x; l.color[1] = color.y; l.color[2] = color.z;
     l.area = objs.objs[prim_index].area(objs);
+    l.xform_index = -1;
+    return l;
+}
+rt_light Light::make_infinite_light(Objects& objs, const Mat4* to_world, uint32_t, uint32_t text_id) {
+    rt_light l;
+    std::memset(&l, 0, sizeof(l));
+    l.kind = RT_LIGHT_INFINITE;
+    l.tex_index = text_id;
+    l.world_radius = 10000.0;  // light.rs:636
+    l.xform_index = -1;
+    if (to_world) {
+        rt_xform x;
+        const Mat4 inv = to_world->affine_inverse();  // to_obj = to_world.inverse() (light.rs:609)
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 4; c++) {
+                x.fwd[r * 4 + c] = to_world->m[r * 4 + c];
+                x.inv[r * 4 + c] = inv.m[r * 4 + c];
+            }
+        objs.light_xforms.emplace_back((uint32_t)objs.lights.size(), x);  // the caller pushes the light next
+    }
     return l;
 }
 
@@ -388,7 +554,12 @@ void FlatScene::build(Objects&& objs) {
     }
     materials = std::move(objs.materials);
     textures = std::move(objs.textures);
+    hdr_store = std::move(objs.hdr_store);
     lights = std::move(objs.lights);
+    for (auto& lx : objs.light_xforms) {
+        xforms.push_back(lx.second);
+        lights[lx.first].xform_index = (int32_t)xforms.size() - 1;
+    }
     desc.meshes = meshes.data();       desc.n_meshes = meshes.size();
     desc.prims = prims.data();         desc.n_prims = prims.size();
     desc.xforms = xforms.data();       desc.n_xforms = xforms.size();

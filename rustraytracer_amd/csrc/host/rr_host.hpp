@@ -12,9 +12,11 @@
 //   Material::make_*                       src/material.rs:401-516
 //   Texture::new_solid_color / _checkered  src/material.rs:618-627
 //   Light::make_diffuse_light              src/light.rs:585-606
+//   Texture::new_hdr, Light::make_infinite_light   src/material.rs:631-641, src/light.rs:608-638 (row f4)
 //   scenes::*                              src/scenes.rs
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -30,6 +32,7 @@ struct Vec3 {
 struct Mat4 {
     double m[16];
     static Mat4 identity();
+    static Mat4 from_rows(const double (&r)[16]);                      // Matrix4::new (row-major arguments)
     static Mat4 translation(double x, double y, double z);             // Matrix4::append_translation
     static Mat4 from_euler_angles(double roll, double pitch, double yaw);  // Rotation3::from_euler_angles
     static Mat4 from_scaling(double s);                                // Similarity3::from_scaling
@@ -90,9 +93,19 @@ struct Cube {
     std::vector<Primitive> get_sides() const;
 };
 
+struct Objects;
 namespace Texture {
 rt_texture new_solid_color(Vec3 color);
 rt_texture new_checkered(uint32_t even, uint32_t odd, double frequency);
+// material.rs:631-641 Texture::new_hdr: Radiance .hdr -> Rgb<f32> (image 0.23.12 HdrDecoder::read_image_hdr) ->
+// per texel image::hdr::to_rgbe8, the only form Texture::get_value reads (material.rs:577-585).  The texels are
+// kept alive by `objs`.  Returns false + err when the file cannot be read.
+bool new_hdr(Objects& objs, const std::string& path, rt_texture& out, std::string& err);
+// Deterministic stand-in environment (sky gradient, sun, ground) for machines without the reference's data/
+rt_texture new_hdr_procedural(Objects& objs, uint32_t width, uint32_t height);
+// image::hdr helpers (f32 arithmetic, as the crate): Rgbe8Pixel::to_hdr and to_rgbe8
+void rgbe_to_hdr(const uint8_t* rgbe, float* rgb);
+void hdr_to_rgbe8(const float* rgb, uint8_t* rgbe);
 }  // namespace Texture
 
 namespace Material {
@@ -113,12 +126,17 @@ struct Objects {
     std::vector<rt_light> lights;
     std::vector<rt_material> materials;
     std::vector<rt_texture> textures;
+    std::vector<std::shared_ptr<std::vector<uint8_t>>> hdr_store;  // texels of Texture::Hdr entries
+    std::vector<std::pair<uint32_t, rt_xform>> light_xforms;       // to_world of Light::Infinite entries
 };
 
 namespace Light {
 // src/light.rs:585-606 (to_world is the identity in every preset and is not read on the path)
 rt_light make_diffuse_light(const Objects& objs, uint32_t prim_index, Vec3 color, uint32_t n_samples,
                             bool two_sided, bool is_mesh);
+// src/light.rs:608-638; to_world == nullptr is Projective3::identity().  The Distribution2D the reference
+// builds here is rebuilt by the library at rt_scene_commit from the texture (include/rt_abi.h).
+rt_light make_infinite_light(Objects& objs, const Mat4* to_world, uint32_t n_samples, uint32_t text_id);
 }
 
 // Mesh::generate_triangles (src/hittable.rs:257-288)
@@ -143,6 +161,7 @@ struct FlatScene {
     std::vector<rt_material> materials;
     std::vector<rt_texture> textures;
     std::vector<rt_light> lights;
+    std::vector<std::shared_ptr<std::vector<uint8_t>>> hdr_store;
     rt_scene_desc desc;
     Camera camera;
     std::string name;

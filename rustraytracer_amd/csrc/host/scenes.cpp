@@ -261,7 +261,93 @@ static bool two_dragons(const PresetParams& p, FlatScene& out, std::string& err)
     return true;
 }
 
+// scenes.rs:627-741 material_hdr(mat_num), next-row f4: environment-lit material test.
+// `variant` = mat_num: 0 smooth_plastic, 1 rosegold_metal, 2 mirror, 3 glass (rough, 0.01) -- scenes.rs:805-861.
+// `mesh_path` names the reference's data/material directory (models/Mesh00{0,1,2}.obj, textures/envmap.hdr);
+// whatever is missing there (Mesh002.obj is not in the checkout) or everything, when mesh_path is empty, is
+// replaced by the procedural P-N mesh and the procedural environment of Texture::new_hdr_procedural.
+static bool material_hdr(const PresetParams& p, FlatScene& out, std::string& err) {
+    Objects o;
+    Vec3 from = V(3.04068, 3.17153, 3.20454);
+    Vec3 dir = V(-0.583445, -0.538765, -0.60772);
+    Vec3 to = V(from.x + dir.x, from.y + dir.y, from.z + dir.z);
+    Vec3 up = V(-0.373123, 0.842456, -0.388647);
+    Camera camera = Camera::create(from, to, up, p.aspect_ratio, 20., 0.0, 10.);
+    const std::string root = (p.mesh_path && p.mesh_path[0]) ? std::string(p.mesh_path) : std::string();
+    {
+        rt_texture env;
+        std::string e2;
+        if (root.empty() || !Texture::new_hdr(o, root + "/textures/envmap.hdr", env, e2))
+            env = Texture::new_hdr_procedural(o, 512, 256);
+        o.textures.push_back(env);
+    }
+    o.lights.push_back(Light::make_infinite_light(o, nullptr, 1, 0));
+    const double m1[16] = {0.482906, 0, 0, 0.0571719, 0, 0.482906, 0, 0.213656, 0, 0, 0.482906, 0.0682078, 0, 0, 0, 1};
+    const double m2[16] = {0.482906, 0, 0, 0.156382, 0, 0.482906, 0, 0.777229, 0, 0, 0.482906, 0.161698, 0, 0, 0, 1};
+    const double m0[16] = {0.482906, 0, 0, 0.110507, 0, 0.482906, 0, 0.494301, 0, 0, 0.482906, 0.126194, 0, 0, 0, 1};
+    const double rect_matrix[16] = {-1.88298, 1.9602, 2.50299e-007, -0.708772, -2.37623e-007, 1.18811e-007, -2.71809, 0,
+                                    -1.9602, -1.88298, 8.90586e-008, -0.732108, 0, 0, 0, 1};
+    const Mat4 transform1 = Mat4::from_rows(m1), transform2 = Mat4::from_rows(m2), transform0 = Mat4::from_rows(m0);
+    const Mat4 rect_transform = Mat4::from_rows(rect_matrix);
+    const uint64_t faces = p.mesh_faces ? p.mesh_faces : 60000;
+    auto load = [&](const char* file, const Mat4& trans, double blob, Mesh& m) {
+        std::string e2;
+        if (!root.empty() && parse_obj(root + "/models/" + file, trans, m, e2)) return;
+        m = procedural_mesh(faces, trans * Mat4::from_scaling(blob));  // stand-in, same placement
+    };
+    Mesh mesh1, mesh2, mesh0;
+    load("Mesh001.obj", transform1, 1.3, mesh1);
+    load("Mesh002.obj", transform2, 0.9, mesh2);
+    load("Mesh000.obj", transform0, 1.8, mesh0);
+    o.meshes.push_back(std::move(mesh1));
+    o.meshes.push_back(std::move(mesh2));
+    o.meshes.push_back(std::move(mesh0));
+    uint32_t curr_len = (uint32_t)o.textures.size();
+    switch (p.variant) {
+        case 0:  // smooth_plastic, scenes.rs:805-818
+            o.textures.push_back(Texture::new_solid_color(V(0.1608, 0.0014767, 0.4)));
+            o.textures.push_back(Texture::new_solid_color(white()));
+            o.materials.push_back(Material::make_plastic(curr_len, curr_len + 1, 0, 0.002, false));
+            break;
+        case 1:  // rosegold_metal, scenes.rs:820-838
+            o.textures.push_back(Texture::new_solid_color(V(1.0 - 0.718, 1.0 - 0.431, 1.0 - 0.475)));
+            o.textures.push_back(Texture::new_solid_color(white()));
+            o.textures.push_back(Texture::new_solid_color(V(0.002, 0., 0.)));
+            o.materials.push_back(Material::make_metal(curr_len, curr_len + 1, curr_len + 2, curr_len + 2, curr_len + 2, 0, true));
+            break;
+        case 2:  // mirror, scenes.rs:863-867
+            o.textures.push_back(Texture::new_solid_color(V(1., 1., 1.)));
+            o.materials.push_back(Material::make_mirror(curr_len, 0));
+            break;
+        case 3:  // glass, scenes.rs:843-861
+            o.textures.push_back(Texture::new_solid_color(V(1.0 - 0.718, 1.0 - 0.431, 1.0 - 0.475)));
+            o.textures.push_back(Texture::new_solid_color(white()));
+            o.textures.push_back(Texture::new_solid_color(V(0.002, 0., 0.)));
+            o.materials.push_back(Material::make_glass(curr_len + 1, curr_len + 1, 0.01, 0.01, 1.5, 0, true));
+            break;
+        default:
+            err = "material_hdr: mat_num must be 0..3";  // the reference pushes no material and would panic later
+            return false;
+    }
+    uint32_t len = (uint32_t)o.textures.size();
+    o.textures.push_back(Texture::new_solid_color(scale(white(), 0.2)));
+    o.textures.push_back(Texture::new_solid_color(V(0.325, 0.31, 0.325)));
+    o.textures.push_back(Texture::new_solid_color(V(0.725, 0.71, 0.68)));
+    o.textures.push_back(Texture::new_checkered(len + 1, len + 2, 10.));
+    o.materials.push_back(Material::make_matte(len, 0., 0));
+    o.materials.push_back(Material::make_matte(len + 3, 0., 0));
+    for (auto& t : generate_triangles(o.meshes, 0, 0)) o.objs.push_back(t);
+    for (auto& t : generate_triangles(o.meshes, 1, 0)) o.objs.push_back(t);
+    for (auto& t : generate_triangles(o.meshes, 2, 1)) o.objs.push_back(t);
+    o.objs.push_back(Primitive::new_xy_rect_transform(-1., -1., 1., 1., 0., 2, &rect_transform));
+    out.camera = camera;
+    out.name = "material.png";
+    out.build(std::move(o));
+    return true;
+}
+
 bool build_preset(const std::string& name, const PresetParams& p, FlatScene& out, std::string& err) {
+    if (name == "material_hdr") return material_hdr(p, out, err);
     if (name == "cornell_box") return cornell_box(p, out, err);
     if (name == "cornell_box_spheres") return cornell_box_spheres(p, out, err);
     if (name == "cornell_box_statue") return cornell_box_statue(p, out, err);

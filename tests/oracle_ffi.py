@@ -64,6 +64,8 @@ def lib():
     L.oracle_refract.argtypes = [dp, dp, d, dp]
     L.oracle_lambert_f_pdf.argtypes = [dp, dp, dp, dp, dp]
     L.oracle_microfacet_f_pdf.argtypes = [d, d, dp, dp, dp, dp, dp, dp]
+    L.oracle_micro_trans.argtypes = [d, d, d, dp, dp, dp, d, d, dp, dp, dp, dp, dp]
+    L.oracle_env.argtypes = [vp, C.c_int, dp, dp]
     L.oracle_prim_area.restype = d
     L.oracle_prim_area.argtypes = [vp, C.c_int32]
     L.oracle_prim_pdf.restype = d
@@ -144,6 +146,13 @@ class OracleScene:
         ra = np.frombuffer(rays, dtype=np.float64).reshape(capacity, 8)[:n]
         ha = np.frombuffer(hits, dtype=np.dtype([("t", "<f8"), ("prim", "<i4"), ("r", "<u4")]))[:n]
         return ra[:, 0:3].copy(), ra[:, 3:6].copy(), ra[:, 6].copy(), ha["t"].copy(), ha["prim"].copy()
+
+    def env(self, what, *xs):
+        """Light::Infinite tables: 0 sample(u0,u1)->(uv0,uv1,pdf); 1 pdf(p0,p1); 2 le(dir); 3 pdf_li(dir); 4 sizes"""
+        out = (C.c_double * 3)()
+        rc = lib().oracle_env(self._h, what, vec(*xs) if xs else vec(0.0), out)
+        assert rc == 0, rc
+        return np.array(out[:])
 
     def close(self):
         if self._h:

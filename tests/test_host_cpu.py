@@ -82,9 +82,9 @@ def test_struct_layouts_match_the_header():
     # sizes the C side static_asserts or relies on (include/rt_abi.h)
     assert C.sizeof(F.rt_primitive) == 120
     assert C.sizeof(F.rt_xform) == 192
-    assert C.sizeof(F.rt_texture) == 48
+    assert C.sizeof(F.rt_texture) == 64
     assert C.sizeof(F.rt_material) == 56
-    assert C.sizeof(F.rt_light) == 48
+    assert C.sizeof(F.rt_light) == 64
     assert C.sizeof(F.rt_camera) == 15 * 8 + 9 * 8
     assert C.sizeof(F.rt_ray) == 64 and C.sizeof(F.rt_hit) == 16
     assert C.sizeof(F.rt_render_cfg) == 72
@@ -293,3 +293,77 @@ def test_resolve_rgb8_reference_formula():
     want = [[ref(v) for v in row] for row in [[0.0, 0.18, 1.0], [4.0, 100.0, 0.5]]]
     assert out.tolist() == want
     assert out[0, 0] == 0 and out[1, 1] == 255
+
+
+def _write_hdr(path, w, h, px):
+    """Radiance RGBE file with new-style RLE scanlines; px: (h, w, 4) uint8."""
+    with open(path, "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w))
+        for y in range(h):
+            f.write(bytes([2, 2, w >> 8, w & 255]))
+            for c in range(4):
+                row = px[y, :, c]
+                x = 0
+                while x < w:
+                    run = 1
+                    while x + run < w and run < 127 and row[x + run] == row[x]:
+                        run += 1
+                    if run >= 3:
+                        f.write(bytes([128 + run, int(row[x])]))
+                        x += run
+                    else:
+                        lit = min(w - x, 20)
+                        f.write(bytes([lit]) + bytes(int(v) for v in row[x:x + lit]))
+                        x += lit
+
+
+def test_material_hdr_preset_and_hdr_reader(tmp_path):
+    """scenes.rs:627-741 + Texture::new_hdr (material.rs:631-641): file -> Rgb<f32> -> to_rgbe8 texels."""
+    sc = rr.material_hdr(1, mesh_faces=1000)
+    d = sc.desc.contents
+    assert d.n_lights == 1 and d.lights[0].kind == 1 and d.lights[0].tex_index == 0
+    assert d.lights[0].world_radius == 10000.0 and d.lights[0].xform_index == -1
+    assert d.textures[0].kind == 2 and d.textures[0].width == 512 and d.textures[0].height == 256
+    assert d.n_prims == 3 * 1000 + 1 and d.n_materials == 3 and d.n_textures == 1 + 3 + 4
+    assert d.prims[d.n_prims - 1].kind == 2 and d.prims[d.n_prims - 1].xform_index >= 0   # the transformed floor rect
+    assert d.materials[0].kind == 4 and d.materials[2].kind == 0
+    variants = [rr.material_hdr(k, mesh_faces=500) for k in range(4)]   # kept alive: desc points into them
+    assert [v.desc.contents.materials[0].kind for v in variants] == [2, 4, 5, 3]
+    g = variants[3].desc.contents.materials[0]
+    assert (g.f[0], g.f[1], g.f[2]) == (0.01, 0.01, 1.5) and g.remap_roughness == 1
+    with pytest.raises(Exception):
+        rr.material_hdr(7)
+    # a data directory with an envmap: normalised RGBE texels survive the f32 round trip unchanged
+    root = tmp_path / "material"
+    (root / "textures").mkdir(parents=True)
+    rng = np.random.default_rng(2)
+    w, h = 40, 12
+    px = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    px[..., 3] = rng.integers(100, 150, size=(h, w))
+    px[..., 0] |= 128                     # normalised: the largest mantissa has its top bit set
+    px[:, 5:15, :] = px[:, 5:6, :]        # a run, to exercise the RLE branch
+    px[3, 20] = (0, 0, 0, 0)              # black texel
+    px[4, 21] = (7, 3, 1, 130)            # denormalised: to_rgbe8 renormalises (7 -> 224 = x 32, e - 5)
+    _write_hdr(root / "textures" / "envmap.hdr", w, h, px)
+    sc2 = rr.material_hdr(0, mesh_faces=500, data_dir=str(root))
+    t = sc2.desc.contents.textures[0]
+    assert (t.width, t.height) == (w, h)
+    got = np.ctypeslib.as_array(t.rgbe, shape=(h, w, 4))
+    expect = px.copy()
+    expect[4, 21] = (7 * 32, 3 * 32, 1 * 32, 125)
+    assert np.array_equal(got, expect)
+
+
+def test_reference_envmap_if_present():
+    """The reference's own data/material/textures/envmap.hdr (exists only in the build container)."""
+    root = "/root/reference/data/material"
+    if not os.path.exists(root + "/textures/envmap.hdr"):
+        pytest.skip("reference data not on this machine")
+    sc = rr.material_hdr(2, mesh_faces=500, data_dir=root)
+    d = sc.desc.contents
+    t = d.textures[0]
+    assert t.width >= 256 and t.height * 2 == t.width
+    got = np.ctypeslib.as_array(t.rgbe, shape=(t.height, t.width, 4))
+    assert (got[..., 3] > 0).mean() > 0.9     # a studio map: a few black texels, the rest lit
+    # Mesh000/001.obj are in the checkout, Mesh002.obj is not (-> procedural): 3 meshes either way
+    assert d.n_meshes == 3 and d.meshes[0].n_ind > 3 * 500

@@ -413,3 +413,109 @@ def test_hits_below_tmin_are_not_pruned():
     for mode in (O.ORDERED, O.EXHAUSTIVE):
         t, p = osc.intersect_batch(o, d, g["tmin"], mode=mode)
         assert np.array_equal(p, want_p) and np.array_equal(t, want_t), mode
+
+
+# ------------------------------------------------------------------ next-row f4
+def test_microfacet_transmission_kat(oracle):
+    """bxdf.rs:393-441, 608-638, 742-763 (rough glass).  Hand-derived properties of the restatement."""
+    d3 = lambda: (C.c_double * 3)()
+    f, sf, swi = d3(), d3(), d3()
+    pdf, spdf = C.c_double(), C.c_double()
+    white = O.vec(1, 1, 1)
+    ax = ay = 0.05
+    eta = 1.5
+    wo = np.array([0.3, -0.2, 0.9]); wo /= np.linalg.norm(wo)
+    rng = np.random.default_rng(5)
+    n_ok = 0
+    for _ in range(200):
+        u0, u1 = rng.uniform(size=2)
+        oracle.oracle_micro_trans(ax, ay, eta, white, O.vec(*wo), O.vec(0, 0, -1), u0, u1, f, C.byref(pdf), swi, sf,
+                                  C.byref(spdf))
+        if spdf.value == 0.0:
+            continue
+        n_ok += 1
+        wi = np.array(swi[:])
+        assert wi[2] * wo[2] < 0.0                      # transmission: the other hemisphere
+        assert abs(np.linalg.norm(wi) - 1.0) < 1e-12    # refract() of unit vectors is unit
+        # sample_f's (f, pdf) are exactly Bxdf::f / Bxdf::pdf of the sampled pair (bxdf.rs:631-633)
+        oracle.oracle_micro_trans(ax, ay, eta, white, O.vec(*wo), O.vec(*wi), u0, u1, f, C.byref(pdf), swi, sf,
+                                  C.byref(spdf))
+        assert pdf.value == spdf.value and list(f[:]) == list(sf[:])
+        assert pdf.value > 0.0 and min(f[:]) >= 0.0
+        # generalized half vector: wo + wi * (eta_b/eta_a) is parallel to a micro-normal with wo.wh * wi.wh <= 0
+        wh = wo + wi * (1.0 / eta)
+        wh /= np.linalg.norm(wh)
+        assert np.dot(wo, wh) * np.dot(wi, wh) <= 0.0
+    assert n_ok > 150
+    # same hemisphere -> no transmission (bxdf.rs:402-405, 745-747)
+    oracle.oracle_micro_trans(ax, ay, eta, white, O.vec(*wo), O.vec(0.1, 0.2, 0.97), 0.5, 0.5, f, C.byref(pdf), swi, sf,
+                              C.byref(spdf))
+    assert pdf.value == 0.0 and list(f[:]) == [0.0, 0.0, 0.0]
+    # near-smooth limit: the sampled direction approaches Snell's refraction about +z (eta_a/eta_b = 1.5 entering)
+    out = d3()
+    assert oracle.oracle_refract(O.vec(*wo), O.vec(0, 0, 1), eta, out) in (0, 1)
+    oracle.oracle_micro_trans(1e-3, 1e-3, eta, white, O.vec(0, 0, 1), O.vec(0, 0, -1), 0.3, 0.6, f, C.byref(pdf), swi, sf,
+                              C.byref(spdf))
+    assert swi[2] < -0.9999                              # normal incidence goes straight through
+
+
+def _hdr_scene(num=1):
+    return rr.material_hdr(num, mesh_faces=2000)
+
+
+def test_environment_distribution_kat():
+    """distribution.rs:27-166 + light.rs:204-245, 285-294, 608-638 on the procedural environment."""
+    sc = _hdr_scene()
+    osc = O.OracleScene(sc)
+    nu, nv, marg_int = osc.env(4)
+    tex = sc.desc.contents.textures[0]
+    assert tex.kind == 2 and (nu, nv) == (2 * tex.width, 2 * tex.height) and marg_int > 0.0
+    rng = np.random.default_rng(11)
+    for _ in range(300):
+        u0, u1 = rng.uniform(size=2)
+        uv0, uv1, pdf = osc.env(0, u0, u1)
+        assert 0.0 <= uv0 < 1.0 and 0.0 <= uv1 < 1.0 and pdf >= 0.0
+        # pdf_1 * pdf_0 = func_v[off]/int_v * int_v/marg_int = the table value Distribution2D::pdf reads
+        assert osc.env(1, uv0, uv1)[0] == pytest.approx(pdf, rel=1e-12)
+    # distribution.rs:118 slices row v as f[v .. v + nu) (not f[v * nu ..]): row 1 is row 0 shifted by one entry.
+    # The restatement keeps it (the estimator stays unbiased: pdf and sampling agree, asserted above).
+    for iu in (0, 5, 100, int(nu) - 2):
+        a = osc.env(1, (iu + 0.5) / nu, 1.5 / nv)[0]
+        b = osc.env(1, (iu + 1.5) / nu, 0.5 / nv)[0]
+        assert a == b
+    # le(): texel lookup through spherical_phi/theta (util.rs:153-167), y-up convention
+    up = osc.env(2, 0.0, 1.0, 0.0)
+    down = osc.env(2, 0.3, -0.9, 0.1)
+    assert up[2] > up[0] and down[0] > down[2]           # blue zenith, warm ground of the procedural map
+    # the exact nadir wraps to the top row: acos(-1) / PI > 1 with the truncated PI (Q1), round(v h) % h == 0
+    assert list(osc.env(2, 0.0, -1.0, 0.0)) == list(up)
+    # pdf_li of the zenith: sin(theta) == 0 -> 0 (light.rs:290-292)
+    assert osc.env(3, 0.0, 1.0, 0.0)[0] == 0.0
+    assert osc.env(3, 1.0, 0.2, 0.3)[0] > 0.0
+
+
+def test_hdr_texture_value_formula():
+    """material.rs:570-587: x = round((1-u) w) % w, y = round(v h) % h, (c + 0.5) 2^(e-128) / 256."""
+    sc = _hdr_scene()
+    osc = O.OracleScene(sc)
+    tex = sc.desc.contents.textures[0]
+    w, h = tex.width, tex.height
+    out = O.vec(0, 0, 0)
+    for u, v in ((0.0, 0.0), (0.25, 0.5), (0.999, 0.999), (1.0, 1.0), (0.5, 0.0)):
+        x = int(math.floor((1.0 - u) * w + 0.5)) % w
+        y = int(math.floor(v * h + 0.5)) % h
+        q = [tex.rgbe[4 * (y * w + x) + k] for k in range(4)]
+        O.lib().oracle_texture_value(osc._h, 0, u, v, out)
+        exp = [(q[c] + 0.5) * 2.0 ** (q[3] - 128) / 256.0 for c in range(3)]
+        assert list(out[:]) == exp
+
+
+def test_oracle_renders_environment_lit_scene():
+    sc = _hdr_scene(3)    # rough glass under the environment
+    osc = O.OracleScene(sc)
+    cfg = rr.make_cfg(24, 24, 4)
+    a, na, sa = osc.render(sc.camera, cfg, O.ORDERED)
+    b, nb, sb = osc.render(sc.camera, cfg, O.EXHAUSTIVE)
+    assert np.array_equal(a, b) and sa.rays == sb.rays
+    assert np.isfinite(a).all() and a.mean() > 0.01       # the sky lights everything
+    assert sa.rays_shadow > 0 and sa.rays_probe > 0
