@@ -33,6 +33,12 @@ WORKLOADS = {
            "C2 cornell_box_statue (matte) + procedural P-400k mesh, 512x512 @ 64 spp, max_depth 25"),
     "c3": ("plastic_dragon", dict(mesh_faces=871414, variant=1), 1024, 1024, 256,
            "C3 dragon (procedural P-871k) microfacet metal, 1024x1024 @ 256 spp, max_depth 25"),
+    "c4": ("two_dragons", dict(mesh_faces=871414, variant=0), 1920, 1080, 1024,
+           "C4 two_dragons (glass + metal, 2 x procedural P-871k), 1920x1080 @ 1024 spp, max_depth 25"),
+    "c5": ("plastic_dragon", dict(mesh_faces=871414, variant=2), 2048, 2048, 4096,
+           "C5 dragon (procedural P-871k) smooth glass, 2048x2048 @ 4096 spp, max_depth 25"),
+    "hdr": ("material_hdr", dict(variant=3, mesh_faces=150000), 512, 512, 64,
+            "row f4: material_hdr(3) rough glass under the procedural environment map, 3 x P-150k, 512x512 @ 64 spp"),
     "c1": ("cornell_box", dict(), 256, 256, 16, "C1 cornell_box 256x256 @ 16 spp"),
     "tiny": ("cornell_box_statue", dict(mesh_faces=20000, variant=0), 128, 128, 8, "tiny smoke workload"),
 }

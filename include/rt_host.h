@@ -18,7 +18,9 @@ typedef struct rrh_scene rrh_scene;
 
 /* preset: "cornell_box" (scenes.rs:89-197), "cornell_box_spheres" (C1s),
  * "cornell_box_statue" (scenes.rs:200-307), "plastic_dragon" (scenes.rs:310-375),
- * "sphere_roughness" (scenes.rs:474-546), "two_dragons" (scenes.rs:549-624).
+ * "sphere_roughness" (scenes.rs:474-546), "two_dragons" (scenes.rs:549-624),
+ * "material_hdr" (scenes.rs:627-741; variant = mat_num, mesh_path = the
+ * reference's data/material directory).
  * mesh_faces: procedural stand-in face count (0 = preset default);
  * mesh_path: OBJ to load instead (NULL = procedural); variant: see scenes.cpp.   */
 int rrh_scene_build(const char* preset, double aspect_ratio, uint64_t mesh_faces, const char* mesh_path,
@@ -42,6 +44,11 @@ int rrh_scene_upload_ex(rt_context* ctx, const rt_scene_desc* desc, uint32_t com
 int rrh_gpu_tile(rt_context* ctx, rt_scene* scene, const rt_camera* camera, uint32_t width, uint32_t height,
                  uint32_t samples_per_pixel, uint32_t max_depth, uint64_t seed, double* rgb_sum, uint32_t* n,
                  rt_stats* stats);
+
+/* util::draw_picture's last step (src/util.rs:387-398 saves through the `image`
+ * crate): the 8-bit picture of rt_resolve_rgb8 as an RGB PNG (8 bits, no
+ * interlace, stored deflate blocks).  Next-row f1.                               */
+int rrh_write_png(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height);
 
 #ifdef __cplusplus
 }

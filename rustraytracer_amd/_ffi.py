@@ -138,7 +138,7 @@ ABI_SYMBOLS = [
 ]
 HOST_SYMBOLS = [
     "rrh_scene_build", "rrh_scene_destroy", "rrh_scene_desc", "rrh_scene_camera", "rrh_scene_name",
-    "rrh_last_error", "rrh_camera_new", "rrh_scene_upload", "rrh_scene_upload_ex", "rrh_gpu_tile",
+    "rrh_last_error", "rrh_camera_new", "rrh_scene_upload", "rrh_scene_upload_ex", "rrh_gpu_tile", "rrh_write_png",
 ]
 
 _lib = None
@@ -186,6 +186,7 @@ def lib():
     L.rrh_scene_camera.argtypes = [vp]
     L.rrh_camera_new.argtypes = [C.POINTER(C.c_double)] * 3 + [C.c_double] * 6 + [C.POINTER(rt_camera)]
     L.rrh_scene_upload.argtypes = [vp, C.POINTER(rt_scene_desc), C.POINTER(vp)]
+    L.rrh_write_png.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
     L.rrh_scene_upload_ex.argtypes = [vp, C.POINTER(rt_scene_desc), C.c_uint32, C.POINTER(vp)]
     L.rrh_gpu_tile.argtypes = [vp, vp, C.POINTER(rt_camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                C.c_uint64, vp, vp, C.POINTER(rt_stats)]

@@ -202,3 +202,10 @@ def material_hdr(mat_num=0, aspect_ratio=1.0, mesh_faces=0, data_dir=None):
     """scenes.rs:627-741 (row f4): environment-lit material test; mat_num 0 plastic / 1 metal / 2 mirror /
     3 rough glass.  data_dir = the reference's data/material directory; missing files -> procedural stand-ins."""
     return Scene("material_hdr", aspect_ratio, mesh_faces, data_dir, mat_num)
+
+
+def write_png(path, rgb8):
+    """rgb8: (H, W, 3) uint8 (Context.resolve_rgb8) -> PNG file, the last step of util::draw_picture (row f1)."""
+    rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    h, w, _ = rgb8.shape
+    _check(F.lib().rrh_write_png(str(path).encode(), rgb8.ctypes.data_as(C.c_void_p), w, h), host=True)

@@ -4,9 +4,12 @@
 //   rrh_gpu_tile()  <->  render::tile_multithread(path, camera, sampler, int_type)
 //                        src/render.rs:13-159, with IntType::Path{max_depth,
 //                        invisible_light:false} (src/main.rs:262-265).
+#include <cstdio>
 #include <cstring>
 #include <new>
 #include <string>
+#include <algorithm>
+#include <vector>
 
 #include "../../../include/rt_host.h"
 #include "rr_host.hpp"
@@ -98,6 +101,79 @@ int rrh_gpu_tile(rt_context* ctx, rt_scene* scene, const rt_camera* camera, uint
     cfg.tile_size = 16;  // consts.rs:10
     cfg.tile_world = 1;
     return rt_render(ctx, scene, camera, &cfg, rgb_sum, n, stats);
+}
+
+
+// ---- PNG (RFC 2083) with stored deflate blocks (RFC 1951 3.2.4): no compression library needed
+static uint32_t crc32_update(uint32_t crc, const uint8_t* p, size_t n) {
+    static uint32_t table[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        init = true;
+    }
+    for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 0xffu] ^ (crc >> 8);
+    return crc;
+}
+static void put_be32(std::vector<uint8_t>& v, uint32_t x) {
+    v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x);
+}
+static void put_chunk(std::vector<uint8_t>& out, const char* type, const std::vector<uint8_t>& data) {
+    put_be32(out, (uint32_t)data.size());
+    const size_t start = out.size();
+    out.insert(out.end(), type, type + 4);
+    out.insert(out.end(), data.begin(), data.end());
+    put_be32(out, crc32_update(0xffffffffu, &out[start], out.size() - start) ^ 0xffffffffu);
+}
+
+int rrh_write_png(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height) {
+    if (!path || !rgb8 || width == 0 || height == 0) {
+        g_host_err = "rrh_write_png: bad argument";
+        return RT_ERR_INVALID_ARG;
+    }
+    // raw scanlines: filter byte 0 + RGB
+    std::vector<uint8_t> raw;
+    raw.reserve((size_t)height * (1 + 3 * (size_t)width));
+    for (uint32_t y = 0; y < height; y++) {
+        raw.push_back(0);
+        raw.insert(raw.end(), rgb8 + (size_t)y * width * 3, rgb8 + (size_t)(y + 1) * width * 3);
+    }
+    std::vector<uint8_t> z;  // zlib stream: header, stored blocks of <= 65535 bytes, adler32
+    z.push_back(0x78); z.push_back(0x01);
+    uint32_t a = 1, b = 0;
+    for (size_t pos = 0; pos < raw.size();) {
+        const size_t n = std::min<size_t>(65535, raw.size() - pos);
+        z.push_back(pos + n == raw.size() ? 1 : 0);
+        z.push_back((uint8_t)(n & 0xff)); z.push_back((uint8_t)(n >> 8));
+        z.push_back((uint8_t)(~n & 0xff)); z.push_back((uint8_t)((~n >> 8) & 0xff));
+        z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
+        for (size_t i = 0; i < n; i++) {
+            a = (a + raw[pos + i]) % 65521u;
+            b = (b + a) % 65521u;
+        }
+        pos += n;
+    }
+    put_be32(z, (b << 16) | a);
+    std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    std::vector<uint8_t> ihdr;
+    put_be32(ihdr, width);
+    put_be32(ihdr, height);
+    ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    put_chunk(out, "IHDR", ihdr);
+    put_chunk(out, "IDAT", z);
+    put_chunk(out, "IEND", {});
+    FILE* f = std::fopen(path, "wb");
+    if (!f || std::fwrite(out.data(), 1, out.size(), f) != out.size()) {
+        if (f) std::fclose(f);
+        g_host_err = std::string("rrh_write_png: cannot write ") + path;
+        return RT_ERR_INVALID_ARG;
+    }
+    std::fclose(f);
+    return RT_OK;
 }
 
 }  // extern "C"

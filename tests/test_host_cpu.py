@@ -367,3 +367,38 @@ def test_reference_envmap_if_present():
     assert (got[..., 3] > 0).mean() > 0.9     # a studio map: a few black texels, the rest lit
     # Mesh000/001.obj are in the checkout, Mesh002.obj is not (-> procedural): 3 meshes either way
     assert d.n_meshes == 3 and d.meshes[0].n_ind > 3 * 500
+
+
+def _read_png(path):
+    """Minimal reader for what rrh_write_png emits (8-bit RGB, filter 0) using zlib only."""
+    import struct
+    import zlib
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w, h = 8, b"", 0, 0
+    while pos < len(data):
+        n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        crc, = struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])
+        assert zlib.crc32(typ + body) == crc
+        if typ == b"IHDR":
+            w, h, depth, ctype, comp, filt, inter = struct.unpack(">IIBBBBB", body)
+            assert (depth, ctype, comp, filt, inter) == (8, 2, 0, 0, 0)
+        elif typ == b"IDAT":
+            idat += body
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(h, 1 + 3 * w)
+    assert (raw[:, 0] == 0).all()
+    return raw[:, 1:].reshape(h, w, 3)
+
+
+def test_png_writer_round_trip(tmp_path):
+    """next-row f1: the 8-bit picture leaves as a PNG (util.rs:387-398); checked with zlib's own crc/adler/inflate."""
+    rng = np.random.default_rng(4)
+    for w, h in ((1, 1), (37, 19), (300, 200)):   # the last one spans several 64 KiB stored blocks
+        img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        p = tmp_path / f"t{w}.png"
+        rr.write_png(p, img)
+        assert np.array_equal(_read_png(p), img)
+    with pytest.raises(Exception):
+        rr.write_png(tmp_path / "no_such_dir" / "x.png", img)
