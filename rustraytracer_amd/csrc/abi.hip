@@ -828,6 +828,22 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
         stats->kernel_ms = kernel_ms;
         stats->trace_ms = trace_ms;
         stats->trace_launches = trace_launches;
+#ifdef RT_SHADE_PROF
+        {
+            unsigned long long pr[16];
+            if (hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_shade_prof), sizeof(pr)) == hipSuccess) {
+                static const char* names[10] = {"a:load+fold", "a:record", "a:emitted", "b:scattering", "b:nee-light",
+                                                "b:nee-bsdf", "b:continue", "b:store", "alloc", "queue"};
+                unsigned long long tot = 0;
+                for (int i = 0; i < 10; i++) tot += pr[i];
+                fprintf(stderr, "[shade prof] wave-cycles (100 MHz ticks) total %llu:", tot);
+                for (int i = 0; i < 10; i++) fprintf(stderr, " %s %.1f%%", names[i], tot ? 100.0 * pr[i] / tot : 0.0);
+                fprintf(stderr, "\n");
+                unsigned long long z[16] = {0};
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_shade_prof), z, sizeof(z));
+            }
+        }
+#endif
         if (getenv("RT_DIAG")) {
             unsigned long long d[4] = {0, 0, 0, 0};
             for (int i = 0; i < kStatShards; i++)

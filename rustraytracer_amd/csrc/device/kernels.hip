@@ -358,6 +358,41 @@ __global__ __launch_bounds__(256) void k_intersect_batch(DevScene sc, const rt_r
 //   shade_b: BSDF, one-light NEE + MIS (integrator.rs:530-634), continuation sample, Russian roulette
 //            (integrator.rs:421-442); writes the survivor's state to slot `os` of `out`.
 // k_shade runs them for one bounce of every path; k_tail loops them per lane until the path retires.
+// Diagnostic build (-DRT_SHADE_PROF via tools/variants.sh, selected with RT_AMD_LIB): wave clock per section of
+// the shading code, printed by rt_render.  Note that time at the block barriers (sections "alloc", "queue") is
+// the wait for the slowest wave of the block, not issue time.
+#ifdef RT_SHADE_PROF
+__device__ unsigned long long g_shade_prof[16];
+struct ShadeProf {
+    unsigned long long acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long last = 0;
+};
+#define RT_PROF_DECL ShadeProf prof_; prof_.last = __builtin_readcyclecounter();
+#define RT_PROF_ARG , ShadeProf& prof_
+#define RT_PROF_PASS , prof_
+#define RT_PROF(k)                                                 \
+    {                                                              \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        prof_.acc[k] += now_ - prof_.last;                         \
+        prof_.last = now_;                                         \
+    }
+#define RT_PROF_FLUSH                                                                       \
+    for (int k_ = 0; k_ < 10; k_++) {                                                       \
+        unsigned long long v_ = prof_.acc[k_];                                              \
+        for (int o_ = 32; o_ > 0; o_ >>= 1) {                                               \
+            const unsigned long long w_ = __shfl_xor(v_, o_, 64);                           \
+            v_ = w_ > v_ ? w_ : v_;                                                         \
+        }                                                                                   \
+        if ((threadIdx.x & 63u) == 0 && v_) atomicAdd(&g_shade_prof[k_], v_);               \
+    }
+#else
+#define RT_PROF_DECL
+#define RT_PROF_ARG
+#define RT_PROF_PASS
+#define RT_PROF(k)
+#define RT_PROF_FLUSH
+#endif
+
 struct ShadeA {
     D3 L, o, d, beta;
     HitRec rec;
@@ -366,7 +401,7 @@ struct ShadeA {
 };
 
 template <bool FULL>
-RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool valid, uint32_t max_depth, ShadeA& a) {
+RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool valid, uint32_t max_depth, ShadeA& a RT_PROF_ARG) {
     a.fl = valid ? in.flags[slot] : kDead;
     const uint32_t fl = a.fl;
     a.live = valid && !(fl & kDead);
@@ -407,6 +442,7 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool va
             a.L = a.L + cmul(ld * (double)sc.n_lights, bk);
         }
     }
+    RT_PROF(0)
     // ---- the vertex found by the extension ray
     const bool active = a.live && !(fl & kFoldOnly);
     a.d = black();
@@ -420,6 +456,7 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool va
         a.beta = ld3(in.bx, in.by, in.bz, slot);
         is_some = hp >= 0;
         if (is_some) is_some = prim_intersects(sc, hp, a.o, a.d, kSmall, kInf, a.rec);
+        RT_PROF(1)
         if (a.bounces == 0 || a.spec) {  // integrator.rs:396-411 (Q18)
             if (is_some) {
                 const int32_t li = sc.prims[a.rec.prim].light_index;
@@ -431,6 +468,7 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool va
         }
     }
     a.will_shade = active && is_some && a.bounces < max_depth;
+    RT_PROF(2)
 }
 
 struct ShadeOut {
@@ -440,7 +478,7 @@ struct ShadeOut {
 // Precondition: a.will_shade.  `os` = slot of `out` reserved for this vertex.
 template <bool FULL>
 RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& out, uint32_t slot, uint32_t os,
-                     ShadeA& a) {
+                     ShadeA& a RT_PROF_ARG) {
     const HitRec& rec = a.rec;
     D3 beta = a.beta;
     uint32_t bounces = a.bounces;
@@ -448,6 +486,7 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
     uint64_t rng = in.rng[slot];
     Bsdf bsdf;
     compute_scattering<FULL>(sc, rec, bsdf);
+    RT_PROF(3)
     bool has_sh = false, has_pr = false;
     uint32_t light_num = 0;
     // ---- uniform_sample_one_light / estimate_direct (integrator.rs:530-634)
@@ -495,6 +534,7 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
                 st3(out.spx, out.spy, out.spz, os, sp);
             }
         }
+        RT_PROF(4)
         {
             D3 f2, wi2;
             double spdf;
@@ -521,6 +561,7 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
             }
         }
         if (has_sh || has_pr) st3(out.kx, out.ky, out.kz, os, beta);
+        RT_PROF(5)
     }
     // ---- continuation (integrator.rs:421-442)
     const D3 wo = -a.d;
@@ -542,6 +583,7 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
         }
         bounces = bounces + 1;
     }
+    RT_PROF(6)
     ShadeOut r;
     r.emit_ext = cont;
     r.emit_sh = has_sh;
@@ -561,6 +603,7 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
     } else {
         out.flags[os] = kDead;
     }
+    RT_PROF(7)
     return r;
 }
 
@@ -577,7 +620,8 @@ __global__ __launch_bounds__(256, 2) void k_shade(DevScene sc, PathState in, Pat
     __shared__ uint32_t s_base[2];    // block's base in the next path list / ray queue
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     ShadeA a;
-    shade_a<FULL>(sc, in, slot, slot < n_active, max_depth, a);
+    RT_PROF_DECL
+    shade_a<FULL>(sc, in, slot, slot < n_active, max_depth, a RT_PROF_PASS);
     // a vertex that will be shaded gets its output slot now (dense, block-contiguous); if the path
     // then ends without pending light terms the slot is marked dead and skipped next bounce
     uint32_t os;
@@ -594,8 +638,9 @@ __global__ __launch_bounds__(256, 2) void k_shade(DevScene sc, PathState in, Pat
         for (uint32_t w = 0; w < wave; w++) off += s_cnt[w][0];
         os = off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     }
+    RT_PROF(8)
     ShadeOut r{false, false, false, false};
-    if (a.will_shade) r = shade_b<FULL>(sc, in, out, slot, os, a);
+    if (a.will_shade) r = shade_b<FULL>(sc, in, out, slot, os, a RT_PROF_PASS);
     if (a.live && !r.keep) {  // retired: its radiance goes to the film staging slot of (pixel, sample)
         const uint32_t og = in.orig[slot];
         lfx[og] = a.L.x;
@@ -637,6 +682,8 @@ __global__ __launch_bounds__(256, 2) void k_shade(DevScene sc, PathState in, Pat
         if (r.emit_sh) queue_out[off + ce + (uint32_t)__popcll(ms & below)] = os | (kRayShadow << 30);
         if (r.emit_pr) queue_out[off + ce + cs + (uint32_t)__popcll(mp & below)] = os | (kRayProbe << 30);
     }
+    RT_PROF(9)
+    RT_PROF_FLUSH
 }
 
 // ---------------------------------------------------------------------- tail
@@ -676,10 +723,11 @@ __global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathS
         if (!(fl & kFoldOnly))
             in.hit_prim[slot] = closest_hit<false>(sc, o, ld3(in.dx, in.dy, in.dz, slot), kSmall, kInf, t, ts, &tc);
         ShadeA a;
-        shade_a<FULL>(sc, in, slot, true, max_depth, a);
+        RT_PROF_DECL
+        shade_a<FULL>(sc, in, slot, true, max_depth, a RT_PROF_PASS);
         ShadeOut r{false, false, false, false};
         if (a.will_shade) {
-            r = shade_b<FULL>(sc, in, out, slot, slot, a);
+            r = shade_b<FULL>(sc, in, out, slot, slot, a RT_PROF_PASS);
             n_v++;
         }
         n_r1 += r.emit_ext ? 1u : 0u;
