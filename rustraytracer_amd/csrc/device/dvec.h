@@ -15,6 +15,21 @@
 
 namespace rtd {
 
+// The elementary functions are called from dozens of sites of the shading code; inlined everywhere they blew
+// the shading kernels up to 170-290 KB of code against a 64 KB instruction cache.  One out-of-line copy each:
+#ifndef RT_INLINE_MATH
+RTDN double ni_sin(double x) { return dm_sin(x); }
+RTDN double ni_cos(double x) { return dm_cos(x); }
+RTDN double ni_atan2(double y, double x) { return dm_atan2(y, x); }
+RTDN double ni_acos(double x) { return dm_acos(x); }
+RTDN double ni_log(double x) { return dm_log(x); }
+#define dm_sin ni_sin
+#define dm_cos ni_cos
+#define dm_atan2 ni_atan2
+#define dm_acos ni_acos
+#define dm_log ni_log
+#endif
+
 // consts.rs:30-42
 constexpr double kPi = 3.14159265358979;
 constexpr double kSmall = 0.001;

@@ -607,8 +607,11 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
     return r;
 }
 
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES 2
+#endif
 template <bool FULL>
-__global__ __launch_bounds__(256, 2) void k_shade(DevScene sc, PathState in, PathState out, Ctl* ctl, uint32_t it_abs,
+__global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_shade(DevScene sc, PathState in, PathState out, Ctl* ctl, uint32_t it_abs,
                                                uint32_t max_depth, uint32_t* queue_out, double* lfx, double* lfy,
                                                double* lfz, DevStats* stats) {
     const uint32_t it = it_abs % kRing, itn = (it_abs + 1) % kRing;
