@@ -212,7 +212,20 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
     }
     // a block only joins the work-pulling loop if the queue can give it at least one batch:
     // tail iterations with a handful of rays then cost a launch, not a grid of atomics
-    if (blockIdx.x * 256u >= n || sc.n_nodes == 0) return;
+    if (sc.n_nodes == 0) {  // a scene without primitives (an environment only): every query misses
+        for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+            const uint32_t e = queue[i];
+            const uint32_t slot = e & kSlotMask, kind = e >> 30;
+            if (kind == kRayExt)
+                st.hit_prim[slot] = -1;
+            else if (kind == kRayShadow)
+                st.sh_prim[slot] = -1;
+            else
+                st.pr_prim[slot] = -1;
+        }
+        return;
+    }
+    if (blockIdx.x * 256u >= n) return;
     const uint32_t lane = threadIdx.x & 63u;
     TravCount tc{0, 0, 0};
     __shared__ int2 lds_stack[kLdsStack * 256];
@@ -702,7 +715,7 @@ __global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathS
     __shared__ int2 lds_stack[kLdsStack * 256];
     const uint32_t n_active = ctl->n_active[it_abs % kRing];
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= n_active || sc.n_nodes == 0) return;
+    if (slot >= n_active) return;  // (closest_hit answers -1 for a scene without primitives)
     TravStack ts;
     ts.lds = &lds_stack[threadIdx.x];
     ts.lds_stride = 256;

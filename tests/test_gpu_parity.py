@@ -266,7 +266,41 @@ def test_abi_error_paths_on_device(gpu_ctx):
     st = F.rt_stats()
     assert L.rt_render(gpu_ctx._h, gs._h, sc.camera, C.byref(rr.make_cfg(16, 16, 2)), None, None, C.byref(st)) == 0
     assert st.paths == 16 * 16 * 2
+    # accumulate needs the caller's film; unknown commit flags are refused
+    acc = rr.make_cfg(16, 16, 2, accumulate=True)
+    assert L.rt_render(gpu_ctx._h, gs._h, sc.camera, C.byref(acc), None, None, None) == F.RT_ERR_INVALID_ARG
     gs.close()
+    h = C.c_void_p()
+    assert L.rt_scene_create(gpu_ctx._h, C.byref(h)) == 0
+    assert L.rt_scene_commit_ex(h, 0x40) == F.RT_ERR_INVALID_ARG
+    # row f4 validation: HDR texture without texels; infinite light whose texture is not an HDR map; two of them
+    t = F.rt_texture()
+    t.kind, t.width, t.height = 2, 4, 2
+    assert L.rt_scene_set_textures(h, C.byref(t), 1) == F.RT_ERR_INVALID_ARG
+    texels = (C.c_uint8 * 32)(*([128, 128, 128, 129] * 8))
+    t.rgbe = C.cast(texels, C.POINTER(C.c_uint8))
+    solid = F.rt_texture()
+    texs = (F.rt_texture * 2)(t, solid)
+    assert L.rt_scene_set_textures(h, texs, 2) == 0
+    lt = (F.rt_light * 2)()
+    for k in (0, 1):
+        lt[k].kind, lt[k].tex_index, lt[k].xform_index, lt[k].world_radius = 1, 1, -1, 10000.0
+    assert L.rt_scene_set_lights(h, lt, 1) == 0
+    assert L.rt_scene_commit(h) == F.RT_ERR_INVALID_ARG and b"RT_TEX_HDR" in L.rt_last_error()
+    lt[0].tex_index = lt[1].tex_index = 0
+    assert L.rt_scene_set_lights(h, lt, 2) == 0
+    assert L.rt_scene_commit(h) == F.RT_ERR_UNSUPPORTED and b"more than one infinite" in L.rt_last_error()
+    # a scene that is nothing but an environment: every primary ray escapes and returns le(ray)
+    assert L.rt_scene_set_lights(h, lt, 1) == 0
+    assert L.rt_scene_commit_ex(h, F.RT_COMMIT_DEVICE_LBVH) == 0
+    rgb = np.zeros((8, 8, 3))
+    cnt = np.zeros((8, 8), dtype=np.uint32)
+    assert L.rt_render(gpu_ctx._h, h, sc.camera, C.byref(rr.make_cfg(8, 8, 4)), rgb.ctypes.data_as(C.c_void_p),
+                       cnt.ctypes.data_as(C.c_void_p), C.byref(st)) == 0
+    # every texel is (128.5, 128.5, 128.5) * 2^(129-128) / 256
+    assert (cnt == 4).all() and np.array_equal(rgb, np.full((8, 8, 3), 4 * 128.5 * 2.0 / 256.0))
+    assert st.rays_extension == 8 * 8 * 4 and st.rays_shadow == 0 and st.vertices_shaded == 0
+    L.rt_scene_destroy(h)
 
 
 def test_golden_rays_below_tmin(gpu_ctx):
