@@ -40,8 +40,8 @@ def stage(tag):
 def collect(tag, rnd):
     src = os.path.join(ROOT, "gpurun_out", "refresh_" + tag)
     prof = os.path.join(ROOT, "profiles")
-    ks = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
-    assert ks, "no kernel_stats.csv"
+    ks = sorted(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")), key=os.path.getmtime, reverse=True)
+    assert ks, "no kernel_stats.csv"   # (gpurun merges into gpurun_out/, so older runs may still be there: newest wins)
     shutil.copy(ks[0], os.path.join(prof, f"{rnd}_kernel_stats_{tag}.csv"))
     shutil.copy(os.path.join(src, "pmc_summary.json"), os.path.join(prof, f"{rnd}_pmc_summary_{tag}.json"))
     shutil.copy(os.path.join(src, "bench_full.json"), os.path.join(prof, f"{rnd}_bench_{tag}.json"))
