@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -65,8 +66,14 @@ struct Builder {
     std::vector<uint32_t> order;  // primitive ids, partitioned in place
     std::vector<double> cx, cy, cz;
     std::vector<BinNode> bin;
+    uint32_t sah_depth = 32;  // experiment knobs: RT_BVH_SAH_DEPTH, RT_BVH_BINS
+    int n_bins = 16;
+    size_t max_leaf = (size_t)kLeafTargetPrims;  // RT_BVH_LEAF
 
     Builder(const rt_primitive* p, size_t n) : prims(p) {
+        if (const char* e = getenv("RT_BVH_SAH_DEPTH")) sah_depth = (uint32_t)std::max(1, atoi(e));
+        if (const char* e = getenv("RT_BVH_BINS")) n_bins = std::min(64, std::max(2, atoi(e)));
+        if (const char* e = getenv("RT_BVH_LEAF")) max_leaf = (size_t)std::min(kMaxLeafPrims, std::max(1, atoi(e)));
         order.resize(n);
         cx.resize(n);
         cy.resize(n);
@@ -97,9 +104,9 @@ struct Builder {
         // Spheres and rects are large, few and expensive to test: each gets a leaf of its own, so that the
         // (4-at-once) box tests and the front-to-back order prune them instead of a leaf loop testing all.
         bool any_other = false;
-        for (size_t i = b; i < e && n <= (size_t)kMaxLeafPrims; i++)
+        for (size_t i = b; i < e && n <= max_leaf; i++)
             any_other = any_other || prims[order[i]].kind != RT_PRIM_TRIANGLE;
-        if (n <= (size_t)kMaxLeafPrims && (n == 1 || !any_other)) {
+        if (n <= max_leaf && (n == 1 || !any_other)) {
             bin[me].is_leaf = true;
             bin[me].leaf_ref = -1 - (int32_t)((uint32_t)(b * 8 + (n - 1)) | (any_other ? kLeafCodeOther : 0u));
             return me;
@@ -118,15 +125,16 @@ struct Builder {
             }
         size_t mid = b;
         bool split_done = false;
-        if (depth < 18) {  // SAH above, object median below: total binary depth <= 18 + ceil(log2(N/4)) <= 40
-            constexpr int NB = 16;
+        if (depth < sah_depth) {  // SAH above, object median below: total binary depth <= sah_depth + ceil(log2(N/4))
+            constexpr int NBMAX = 64;
+            const int NB = n_bins;
             double best_cost = std::numeric_limits<double>::infinity();
             int best_axis = -1, best_bin = -1;
             for (int a = 0; a < 3; a++) {
                 double ext = cmx[a] - cmn[a];
                 if (!(ext > 0.0)) continue;
-                Box bb[NB];
-                size_t cnt[NB];
+                Box bb[NBMAX];
+                size_t cnt[NBMAX];
                 for (int k = 0; k < NB; k++) {
                     bb[k].reset();
                     cnt[k] = 0;
@@ -138,8 +146,8 @@ struct Builder {
                     cnt[k]++;
                     bb[k].grow(prims[order[i]].bbox_min, prims[order[i]].bbox_max);
                 }
-                double right_area[NB];
-                size_t right_cnt[NB];
+                double right_area[NBMAX];
+                size_t right_cnt[NBMAX];
                 Box acc;
                 acc.reset();
                 size_t c = 0;
@@ -257,12 +265,12 @@ struct Collapser {
 
 }  // namespace
 
-void build_bvh(const rt_primitive* prims, size_t n, BvhOut& out) {
+static void build_once(const rt_primitive* prims, size_t n, uint32_t sah_depth_cap, BvhOut& out) {
     out.nodes.clear();
     out.order.clear();
     out.depth = 0;
-    if (n == 0) return;
     Builder bd(prims, n);
+    bd.sah_depth = std::min(bd.sah_depth, sah_depth_cap);
     const int32_t root = bd.build(0, n, 0);
     out.nodes.reserve(bd.bin.size() / 2 + 2);
     if (bd.bin[root].is_leaf) {
@@ -280,6 +288,20 @@ void build_bvh(const rt_primitive* prims, size_t n, BvhOut& out) {
         out.depth = col.max_depth;
     }
     out.order = std::move(bd.order);
+}
+
+void build_bvh(const rt_primitive* prims, size_t n, BvhOut& out) {
+    out.nodes.clear();
+    out.order.clear();
+    out.depth = 0;
+    if (n == 0) return;
+    // SAH splits as deep as the traversal stack allows: an adversarial distribution (SAH peeling one primitive
+    // per level) is rebuilt with SAH confined to fewer top levels and object-median splits below, which bound
+    // the binary depth by cap + ceil(log2 n).
+    for (uint32_t cap : {64u, 16u, 8u, 0u}) {
+        build_once(prims, n, cap, out);
+        if (out.depth + 1 <= (uint32_t)kMaxBvhDepth) return;
+    }
 }
 
 }  // namespace rtd

@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void kb_refit(const rt_primitive* __restrict__
 
 // ---- 4-wide emission, one level per launch.  Work item = (binary node) | (4-wide node index << 32).
 __device__ inline bool leafable(const Tree& t, int32_t c) {
-    return t.all_tri[c] != 0u && t.last[c] - t.first[c] + 1u <= (uint32_t)kMaxLeafPrims;
+    return t.all_tri[c] != 0u && t.last[c] - t.first[c] + 1u <= (uint32_t)kLeafTargetPrims;
 }
 __device__ inline double box_area(const double* b) {
     const double dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
