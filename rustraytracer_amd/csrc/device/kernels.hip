@@ -415,14 +415,22 @@ struct ShadeA {
 
 template <bool FULL>
 RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool valid, uint32_t max_depth, ShadeA& a RT_PROF_ARG) {
-    a.fl = valid ? in.flags[slot] : kDead;
+    // Every field of the slot this function may need is fetched up front, unconditionally: the loads are
+    // independent and coalesced, so they cost one memory latency instead of one per branch level below.
+    const uint32_t ls = valid ? slot : 0u;  // (slot 0 always exists: the block would have exited otherwise)
+    const uint32_t fl_raw = in.flags[ls];
+    const D3 l_in = ld3(in.lx, in.ly, in.lz, ls), o_in = ld3(in.ox, in.oy, in.oz, ls);
+    const D3 d_in = ld3(in.dx, in.dy, in.dz, ls), beta_in = ld3(in.bx, in.by, in.bz, ls);
+    const int32_t hp_in = in.hit_prim[ls], sh_in = in.sh_prim[ls], pp_in = in.pr_prim[ls];
+    const D3 a_in = ld3(in.ax, in.ay, in.az, ls), q_in = ld3(in.qx, in.qy, in.qz, ls), k_in = ld3(in.kx, in.ky, in.kz, ls);
+    a.fl = valid ? fl_raw : kDead;
     const uint32_t fl = a.fl;
     a.live = valid && !(fl & kDead);
     a.L = black();
     a.o = black();
     if (a.live) {
-        a.L = ld3(in.lx, in.ly, in.lz, slot);
-        a.o = ld3(in.ox, in.oy, in.oz, slot);
+        a.L = l_in;
+        a.o = o_in;
         // ---- fold the previous vertex's direct lighting
         if (fl & (kHasShadow | kHasProbe)) {
             const uint32_t light_idx = fl >> kLightShift;
@@ -431,14 +439,14 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool va
             D3 ld = black();
             if (fl & kHasShadow) {
                 // Visibility::unoccluded(infinite): an area light must be the closest hit, the environment needs a miss
-                const int32_t sh = in.sh_prim[slot];
-                if (infinite ? sh < 0 : sh == (int32_t)lt.prim_index) ld = ld + ld3(in.ax, in.ay, in.az, slot);
+                const int32_t sh = sh_in;
+                if (infinite ? sh < 0 : sh == (int32_t)lt.prim_index) ld = ld + a_in;
             }
             if (fl & kHasProbe) {
-                const int32_t pp = in.pr_prim[slot];
+                const int32_t pp = pp_in;
                 if (infinite) {
                     // integrator.rs:617-630: an escaped probe sees light.le(ray), already folded into q by shade_b
-                    if (pp < 0) ld = ld + ld3(in.qx, in.qy, in.qz, slot);
+                    if (pp < 0) ld = ld + q_in;
                 } else if (pp >= 0) {
                     const int32_t li = sc.prims[pp].light_index;
                     if (li >= 0 && (uint32_t)li == light_idx) {
@@ -446,13 +454,12 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool va
                         HitRec nh;
                         if (prim_intersects(sc, pp, a.o, pd, kSmall, kInf, nh)) {
                             const D3 col = light_l(sc.lights[li], nh.n, -pd);  // new_record.le(-wi)
-                            if (!is_black(col)) ld = ld + ld3(in.qx, in.qy, in.qz, slot);
+                            if (!is_black(col)) ld = ld + q_in;
                         }
                     }
                 }
             }
-            const D3 bk = ld3(in.kx, in.ky, in.kz, slot);
-            a.L = a.L + cmul(ld * (double)sc.n_lights, bk);
+            a.L = a.L + cmul(ld * (double)sc.n_lights, k_in);
         }
     }
     RT_PROF(0)
@@ -464,9 +471,9 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool va
     a.bounces = fl & kBounceMask;
     a.spec = (fl & kSpecular) != 0;
     if (active) {
-        const int32_t hp = in.hit_prim[slot];
-        a.d = ld3(in.dx, in.dy, in.dz, slot);
-        a.beta = ld3(in.bx, in.by, in.bz, slot);
+        const int32_t hp = hp_in;
+        a.d = d_in;
+        a.beta = beta_in;
         is_some = hp >= 0;
         if (is_some) is_some = prim_intersects(sc, hp, a.o, a.d, kSmall, kInf, a.rec);
         RT_PROF(1)
