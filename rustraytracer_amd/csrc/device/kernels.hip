@@ -241,9 +241,11 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
     bool exhausted = false;  // wave-uniform: the queue and this wave's reservation have no more entries
     uint32_t slot_kind = 0;
     uint32_t res_next = 0, res_end = 0;  // wave-uniform: [res_next, res_end) is reserved for this wave
+    uint32_t res_base = 0, q_lo = 0, q_hi = 0;  // start of the reservation; its queue entries, two per lane
     // small queues: shrink the reservation so that the tail still spreads over the waves
     const uint32_t n_waves = gridDim.x * 4u;
     uint32_t reserve = (uint32_t)tune.reserve;
+    if (reserve > 128u) reserve = 128u;  // two cached entries per lane
     while (reserve > 64u && (uint64_t)reserve * n_waves * 4u > n) reserve >>= 1;
     for (;;) {
         const unsigned long long idle = __ballot(!has_ray);
@@ -259,6 +261,11 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
                     res_end = res_next;
                     exhausted = true;
                 }
+                // the reservation's queue entries are fetched once, two per lane (reserve <= 128), and handed out
+                // with cross-lane reads: a refill then waits for the ray data only, not for queue -> ray data
+                res_base = base;
+                q_lo = base + lane < res_end ? queue[base + lane] : 0u;
+                q_hi = base + 64u + lane < res_end ? queue[base + 64u + lane] : 0u;
             }
             if (!exhausted) {
                 const uint32_t base = res_next;
@@ -266,8 +273,10 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
                 res_next += take;
                 const uint32_t my = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                 const uint32_t idx = base + my;
+                const uint32_t rel = idx - res_base;  // < 128 for the lanes that take an entry
+                const uint32_t e_lo = __shfl(q_lo, (int)(rel & 63u), 64), e_hi = __shfl(q_hi, (int)(rel & 63u), 64);
                 if (!has_ray && my < take) {
-                    const uint32_t e = queue[idx];
+                    const uint32_t e = rel < 64u ? e_lo : e_hi;
                     const uint32_t slot = e & kSlotMask, kind = e >> 30;
                     D3 o = ld3(st.ox, st.oy, st.oz, slot);
                     D3 d;
