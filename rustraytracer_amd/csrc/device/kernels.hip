@@ -419,6 +419,8 @@ struct ShadeA {
     D3 L, o, d, beta;
     HitRec rec;
     uint32_t fl, bounces;
+    uint32_t orig;  // film staging slot of the path
+    uint64_t rng;
     bool live, spec, will_shade;
 };
 
@@ -432,6 +434,8 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool va
     const D3 d_in = ld3(in.dx, in.dy, in.dz, ls), beta_in = ld3(in.bx, in.by, in.bz, ls);
     const int32_t hp_in = in.hit_prim[ls], sh_in = in.sh_prim[ls], pp_in = in.pr_prim[ls];
     const D3 a_in = ld3(in.ax, in.ay, in.az, ls), q_in = ld3(in.qx, in.qy, in.qz, ls), k_in = ld3(in.kx, in.ky, in.kz, ls);
+    a.rng = in.rng[ls];
+    a.orig = in.orig[ls];
     a.fl = valid ? fl_raw : kDead;
     const uint32_t fl = a.fl;
     a.live = valid && !(fl & kDead);
@@ -512,7 +516,7 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
     D3 beta = a.beta;
     uint32_t bounces = a.bounces;
     bool spec = a.spec;
-    uint64_t rng = in.rng[slot];
+    uint64_t rng = a.rng;
     Bsdf bsdf;
     compute_scattering<FULL>(sc, rec, bsdf);
     RT_PROF(3)
@@ -626,7 +630,7 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
             st3(out.bx, out.by, out.bz, os, beta);
             out.rng[os] = rng;
         }
-        out.orig[os] = in.orig[slot];
+        out.orig[os] = a.orig;
         out.flags[os] = (bounces & kBounceMask) | (spec ? kSpecular : 0u) | (cont ? 0u : kFoldOnly) |
                         (has_sh ? kHasShadow : 0u) | (has_pr ? kHasProbe : 0u) | (light_num << kLightShift);
     } else {
@@ -674,7 +678,7 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_shade(DevScene sc, Path
     ShadeOut r{false, false, false, false};
     if (a.will_shade) r = shade_b<FULL>(sc, in, out, slot, os, a RT_PROF_PASS);
     if (a.live && !r.keep) {  // retired: its radiance goes to the film staging slot of (pixel, sample)
-        const uint32_t og = in.orig[slot];
+        const uint32_t og = a.orig;
         lfx[og] = a.L.x;
         lfy[og] = a.L.y;
         lfz[og] = a.L.z;
@@ -766,7 +770,7 @@ __global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathS
         n_r2 += r.emit_sh ? 1u : 0u;
         n_r3 += r.emit_pr ? 1u : 0u;
         if (!r.keep) {
-            const uint32_t og = in.orig[slot];
+            const uint32_t og = a.orig;
             lfx[og] = a.L.x;
             lfy[og] = a.L.y;
             lfz[og] = a.L.z;
