@@ -111,9 +111,9 @@ static int ensure_lane_capacity(rt_context* c, Lane& ln, uint32_t cap) {
         ln.pool = nullptr;
         ln.capacity = 0;
     }
-    // one slab: 2 x (27 double arrays, rng, 3 result arrays, flags, orig), 2 ray queues
+    // one slab: 2 x (27 double arrays, rng, 4 result arrays, flags, orig), 2 ray queues
     const size_t n = cap;
-    const size_t bytes = n * (2 * (27 * 8 + 8 + 3 * 4 + 4 + 4) + 2 * 3 * 4) + 4096;
+    const size_t bytes = n * (2 * (27 * 8 + 8 + 4 * 4 + 4 + 4) + 2 * 3 * 4) + 4096;
     HIP_TRY(hipMalloc(&ln.pool, bytes));
     char* p = (char*)ln.pool;
     for (int b = 0; b < 2; b++) {
@@ -127,6 +127,7 @@ static int ensure_lane_capacity(rt_context* c, Lane& ln, uint32_t cap) {
         }
         st.rng = (uint64_t*)p; p += n * 8;
         st.hit_prim = (int32_t*)p; p += n * 4;
+        st.hit_slot = (uint32_t*)p; p += n * 4;
         st.sh_prim = (int32_t*)p; p += n * 4;
         st.pr_prim = (int32_t*)p; p += n * 4;
         st.flags = (uint32_t*)p; p += n * 4;
@@ -420,20 +421,25 @@ int rt_scene_commit_ex(rt_scene* s, uint32_t flags) {
     }
     uint64_t n_tri = 0;
     uint32_t depth = 0;
+    bool any_normals = false;
+    for (const auto& m : s->meshes) any_normals = any_normals || !m.n.empty();
+    if (np >= kMetaMatMask || s->mats.size() >= kMetaMatMask) return fail(RT_ERR_UNSUPPORTED, "too many primitives or materials");
     const auto t0 = std::chrono::steady_clock::now();
     if (flags & RT_COMMIT_DEVICE_LBVH) {
         // next-row f3: the tree is built where the primitives already are (bvh_gpu.hip)
         DeviceBvh gb;
         char berr[400] = "";
-        rc = build_bvh_device(s->ctx->stream, d.prims, d.meshes, (uint32_t)np, &gb, berr, sizeof(berr));
+        rc = build_bvh_device(s->ctx->stream, d.prims, d.meshes, (uint32_t)np, any_normals, &gb, berr, sizeof(berr));
         if (rc != RT_OK) return fail(rc, "%s", berr);
-        for (void* p : {(void*)gb.nodes, (void*)gb.leaf_prim, (void*)gb.leaf_tri})
+        for (void* p : {(void*)gb.nodes, (void*)gb.leaf_prim, (void*)gb.leaf_tri, (void*)gb.leaf_nrm, (void*)gb.leaf_meta})
             if (p) s->allocs.push_back(p);
         d.nodes = gb.nodes;
         d.leaf_prim = gb.leaf_prim;
         d.leaf_tri = gb.leaf_tri;
+        d.leaf_nrm = gb.leaf_nrm;
+        d.leaf_meta = gb.leaf_meta;
         d.n_nodes = gb.n_nodes;
-        s->info.device_bytes_total += (uint64_t)gb.n_nodes * sizeof(DevNode) + np * (sizeof(uint32_t) + 9 * sizeof(double));
+        s->info.device_bytes_total += (uint64_t)gb.n_nodes * sizeof(DevNode) + np * (sizeof(uint32_t) + 9 * sizeof(double) + sizeof(LeafMeta) + (any_normals ? 9 * sizeof(double) : 0));
         depth = gb.depth;
         n_tri = gb.n_triangles;
         s->info.build_device_ms = gb.build_ms;
@@ -444,15 +450,21 @@ int rt_scene_commit_ex(rt_scene* s, uint32_t flags) {
         // leaf-ordered triangle vertices + ids
         std::vector<uint32_t> leaf_prim(np);
         std::vector<double> leaf_tri(np * 9, 0.0);
+        std::vector<double> leaf_nrm(any_normals ? np * 9 : 0, 0.0);
+        std::vector<LeafMeta> leaf_meta(np);
         for (size_t i = 0; i < np; i++) {
             const uint32_t id = bvh.order[i];
             const rt_primitive& p = s->prims[id];
+            leaf_meta[i] = LeafMeta{(p.mat_index & kMetaMatMask) | (p.flip ? kMetaFlip : 0u), p.light_index};
             if (p.kind == RT_PRIM_TRIANGLE) {
                 const auto& m = s->meshes[p.mesh_index];
                 for (int v = 0; v < 3; v++) {
                     const uint32_t vi = m.ind[p.tri_ind + v];
                     for (int a = 0; a < 3; a++) leaf_tri[i * 9 + v * 3 + a] = m.p[3 * vi + a];
+                    if (!m.n.empty())
+                        for (int a = 0; a < 3; a++) leaf_nrm[i * 9 + v * 3 + a] = m.n[3 * vi + a];
                 }
+                if (!m.n.empty()) leaf_meta[i].mat_flags |= kMetaHasNormals;
                 leaf_prim[i] = id;
                 n_tri++;
             } else {
@@ -466,6 +478,8 @@ int rt_scene_commit_ex(rt_scene* s, uint32_t flags) {
         if ((rc = upload(s, bvh.nodes.data(), bvh.nodes.size(), &d.nodes)) != RT_OK) return rc;
         if ((rc = upload(s, leaf_prim.data(), leaf_prim.size(), &d.leaf_prim)) != RT_OK) return rc;
         if ((rc = upload(s, leaf_tri.data(), leaf_tri.size(), &d.leaf_tri)) != RT_OK) return rc;
+        if ((rc = upload(s, leaf_nrm.data(), leaf_nrm.size(), &d.leaf_nrm)) != RT_OK) return rc;
+        if ((rc = upload(s, leaf_meta.data(), leaf_meta.size(), &d.leaf_meta)) != RT_OK) return rc;
         d.n_nodes = (uint32_t)bvh.nodes.size();
         depth = bvh.depth;
     }

@@ -463,18 +463,24 @@ __global__ void kb_single(const rt_primitive* __restrict__ prims, DevNode* nodes
 __global__ __launch_bounds__(256) void kb_leaves(const rt_primitive* __restrict__ prims,
                                                  const DevMesh* __restrict__ meshes,
                                                  const uint32_t* __restrict__ order, uint32_t n, uint32_t* leaf_prim,
-                                                 double* leaf_tri) {
+                                                 double* leaf_tri, double* leaf_nrm, LeafMeta* leaf_meta) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t id = order[i];
     const rt_primitive& p = prims[id];
     double* o = leaf_tri + (size_t)i * 9;
+    uint32_t mx = (p.mat_index & kMetaMatMask) | (p.flip ? kMetaFlip : 0u);
+    if (leaf_nrm)
+        for (int a = 0; a < 9; a++) leaf_nrm[(size_t)i * 9 + a] = 0.0;
     if (p.kind == RT_PRIM_TRIANGLE) {
         const DevMesh& m = meshes[p.mesh_index];
         for (int v = 0; v < 3; v++) {
             const uint32_t vi = m.ind[p.tri_ind + v];
             for (int a = 0; a < 3; a++) o[v * 3 + a] = m.p[3 * (size_t)vi + a];
+            if (m.n && leaf_nrm)
+                for (int a = 0; a < 3; a++) leaf_nrm[(size_t)i * 9 + v * 3 + a] = m.n[3 * (size_t)vi + a];
         }
+        if (m.n && leaf_nrm) mx |= kMetaHasNormals;
         leaf_prim[i] = id;
     } else {
         for (int a = 0; a < 5; a++) o[a] = p.v[a];
@@ -483,6 +489,7 @@ __global__ __launch_bounds__(256) void kb_leaves(const rt_primitive* __restrict_
         o[6] = o[7] = o[8] = 0.0;
         leaf_prim[i] = id | kLeafOther;
     }
+    leaf_meta[i] = LeafMeta{mx, p.light_index};
 }
 
 struct Scratch {
@@ -519,7 +526,7 @@ int bfail(char* err, size_t n, int code, const char* fmt, ...) {
     } while (0)
 
 int build_bvh_device(hipStream_t stream, const rt_primitive* d_prims, const DevMesh* d_meshes, uint32_t n,
-                     DeviceBvh* out, char* err, size_t err_len) {
+                     bool any_normals, DeviceBvh* out, char* err, size_t err_len) {
     *out = DeviceBvh{};
     if (n == 0) return RT_OK;
     if (n >= (1u << 27)) return bfail(err, err_len, RT_ERR_UNSUPPORTED, "more than 2^27 primitives");
@@ -566,7 +573,10 @@ int build_bvh_device(hipStream_t stream, const rt_primitive* d_prims, const DevM
     DeviceBvh r;
     B_TRY(keep.get(&r.leaf_prim, n));
     B_TRY(keep.get(&r.leaf_tri, (size_t)n * 9));
-    hipLaunchKernelGGL(kb_leaves, dim3(nb), dim3(256), 0, stream, d_prims, d_meshes, order, n, r.leaf_prim, r.leaf_tri);
+    if (any_normals) B_TRY(keep.get(&r.leaf_nrm, (size_t)n * 9));
+    B_TRY(keep.get(&r.leaf_meta, n));
+    hipLaunchKernelGGL(kb_leaves, dim3(nb), dim3(256), 0, stream, d_prims, d_meshes, order, n, r.leaf_prim, r.leaf_tri,
+                       r.leaf_nrm, r.leaf_meta);
 
     DevNode* pool = nullptr;  // one 4-wide node per binary internal node at most
     const uint32_t max_nodes = n > 1 ? n - 1 : 1;

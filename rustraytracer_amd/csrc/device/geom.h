@@ -30,6 +30,7 @@ struct HitRec {  // hittable.rs:50-72, the fields the path reads
     double u, v;
     uint32_t mat;
     int32_t prim;
+    int32_t light;  // light_index of the primitive
     D3 sh_n, sh_dpdu;
     D3 wo;
 };
@@ -213,14 +214,10 @@ RTD void set_front(HitRec& h, D3 dir) {
 }
 
 // hittable.rs:363-451: the differential-geometry block, run for the winning hit only.
-RTD bool tri_record(const DevScene& sc, const rt_primitive& pr, D3 o, D3 dir, double tmax, HitRec& h) {
-    D3 p0, p1, p2;
-    uint32_t i1, i2, i3;
-    load_tri(sc, pr, p0, p1, p2, i1, i2, i3);
+RTD bool tri_record_core(D3 p0, D3 p1, D3 p2, const TriUv& uv, bool has_n, D3 n1, D3 n2, D3 n3, uint32_t mat, D3 o,
+                         D3 dir, double tmax, HitRec& h) {
     double t, b0, b1, b2;
     if (!tri_core(p0, p1, p2, o, tri_ray(dir), tmax, t, b0, b1, b2)) return false;
-    const DevMesh& m = sc.meshes[pr.mesh_index];
-    TriUv uv = tri_uvs(m, i1, i2, i3);
     D3 dpdu, dpdv;
     if (!tri_dpdu(p0, p1, p2, uv, dpdu, dpdv)) return false;
     D3 dp02 = p0 - p2, dp12 = p1 - p2;
@@ -228,15 +225,11 @@ RTD bool tri_record(const DevScene& sc, const rt_primitive& pr, D3 o, D3 dir, do
     double u_hit = b0 * uv.u0 + b1 * uv.u1 + b2 * uv.u2;
     double v_hit = b0 * uv.v0 + b1 * uv.v1 + b2 * uv.v2;
     D3 normal;
-    if (!m.n) {
+    if (!has_n)
         normal = cross(dp02, dp12);
-    } else {
-        D3 n1 = d3(m.n[3 * i1], m.n[3 * i1 + 1], m.n[3 * i1 + 2]);
-        D3 n2 = d3(m.n[3 * i2], m.n[3 * i2 + 1], m.n[3 * i2 + 2]);
-        D3 n3 = d3(m.n[3 * i3], m.n[3 * i3 + 1], m.n[3 * i3 + 2]);
+    else
         normal = b0 * n1 + b1 * n2 + b2 * n3;
-    }
-    hit_new(h, p_hit, u_hit, v_hit, -dir, dpdu, dpdv, t, pr.mat_index);
+    hit_new(h, p_hit, u_hit, v_hit, -dir, dpdu, dpdv, t, mat);
     h.n = normalize(cross(dp02, dp12));
     h.sh_n = normalize(normal);
     D3 ss = normalize(dpdu);
@@ -256,6 +249,40 @@ RTD bool tri_record(const DevScene& sc, const rt_primitive& pr, D3 o, D3 dir, do
     set_front(h, dir);
     h.u = u_hit;
     h.v = v_hit;
+    return true;
+}
+RTD bool tri_record(const DevScene& sc, const rt_primitive& pr, D3 o, D3 dir, double tmax, HitRec& h) {
+    D3 p0, p1, p2;
+    uint32_t i1, i2, i3;
+    load_tri(sc, pr, p0, p1, p2, i1, i2, i3);
+    const DevMesh& m = sc.meshes[pr.mesh_index];
+    const TriUv uv = tri_uvs(m, i1, i2, i3);
+    D3 n1 = d3(0, 0, 0), n2 = n1, n3 = n1;
+    if (m.n) {
+        n1 = d3(m.n[3 * i1], m.n[3 * i1 + 1], m.n[3 * i1 + 2]);
+        n2 = d3(m.n[3 * i2], m.n[3 * i2 + 1], m.n[3 * i2 + 2]);
+        n3 = d3(m.n[3 * i3], m.n[3 * i3 + 1], m.n[3 * i3 + 2]);
+    }
+    return tri_record_core(p0, p1, p2, uv, m.n != nullptr, n1, n2, n3, pr.mat_index, o, dir, tmax, h);
+}
+// The same record from the triangle's leaf slot (meshes without uvs: default uvs of hittable.rs:455-460)
+RTD bool tri_record_slot(const DevScene& sc, uint32_t ls, int32_t pi, D3 o, D3 dir, double tmax, HitRec& h) {
+    const double* tp = sc.leaf_tri + (size_t)ls * 9;
+    const LeafMeta meta = sc.leaf_meta[ls];
+    const D3 p0 = d3(tp[0], tp[1], tp[2]), p1 = d3(tp[3], tp[4], tp[5]), p2 = d3(tp[6], tp[7], tp[8]);
+    const bool has_n = (meta.mat_flags & kMetaHasNormals) != 0u;
+    D3 n1 = d3(0, 0, 0), n2 = n1, n3 = n1;
+    if (has_n) {
+        const double* np = sc.leaf_nrm + (size_t)ls * 9;
+        n1 = d3(np[0], np[1], np[2]);
+        n2 = d3(np[3], np[4], np[5]);
+        n3 = d3(np[6], np[7], np[8]);
+    }
+    const TriUv uv{0.0, 0.0, 1.0, 0.0, 1.0, 1.0};
+    if (!tri_record_core(p0, p1, p2, uv, has_n, n1, n2, n3, meta.mat_flags & kMetaMatMask, o, dir, tmax, h)) return false;
+    if (meta.mat_flags & kMetaFlip) h.front = !h.front;
+    h.prim = pi;
+    h.light = meta.light;
     return true;
 }
 
@@ -392,7 +419,13 @@ RTD bool prim_intersects(const DevScene& sc, int32_t index, D3 o, D3 dir, double
     if (!intersects_obj(sc, pr, o, dir, tmin, tmax, h)) return false;
     if (pr.flip) h.front = !h.front;
     h.prim = index;
+    h.light = pr.light_index;
     return true;
+}
+// Record of the extension ray's winner: `hs` is the leaf slot the traversal found it in.
+RTD bool hit_record(const DevScene& sc, int32_t index, uint32_t hs, D3 o, D3 dir, double tmin, double tmax, HitRec& h) {
+    if (!(hs & kLeafOther) && !sc.mesh_has_uv) return tri_record_slot(sc, hs, index, o, dir, tmax, h);
+    return prim_intersects(sc, index, o, dir, tmin, tmax, h);
 }
 
 // ---------------------------------------------------------------- traversal
@@ -454,6 +487,7 @@ struct Trav {
     TriRay trr;
     double tmin, tmax, best_t;
     int32_t best_prim, cur;
+    uint32_t best_slot;  // leaf slot of best_prim (| kLeafOther)
     int sp;
     uint32_t leaf_i;
     bool done;
@@ -498,6 +532,7 @@ RTD void trav_init(Trav& tv, const DevScene& sc, D3 o, D3 dir, double tmin, doub
     tv.tmax = tmax;
     tv.best_t = tmax;
     tv.best_prim = -1;
+    tv.best_slot = 0;
     tv.cur = 0;
     tv.sp = 0;
     tv.leaf_i = 0;
@@ -702,6 +737,7 @@ RTD void leaf_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
     if (hit && (tv.best_prim < 0 || t < tv.best_t || (t == tv.best_t && pi > tv.best_prim))) {
         tv.best_t = t;
         tv.best_prim = pi;
+        tv.best_slot = slot | (e & kLeafOther);
     }
     tv.leaf_i++;
     if (tv.leaf_i >= count) trav_pop(tv, ts);
@@ -710,7 +746,7 @@ RTD void leaf_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
 // Closest hit of one ray, run to completion.  Returns prim index or -1; t_out = hit parameter.
 template <bool COUNT>
 RTD int32_t closest_hit(const DevScene& sc, D3 o, D3 dir, double tmin, double tmax, double& t_out, TravStack& ts,
-                        TravCount* tc) {
+                        TravCount* tc, uint32_t* slot_out = nullptr) {
     if (sc.n_nodes == 0) {
         t_out = tmax;
         return -1;
@@ -724,6 +760,7 @@ RTD int32_t closest_hit(const DevScene& sc, D3 o, D3 dir, double tmin, double tm
             leaf_step<COUNT>(tv, sc, ts, tc);
     }
     t_out = tv.best_t;
+    if (slot_out) *slot_out = tv.best_slot;
     return tv.best_prim;
 }
 

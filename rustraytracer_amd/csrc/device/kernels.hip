@@ -328,8 +328,10 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
                 if (steps > 256u) atomicAdd(&stats->pad[5], 1ull);
             }
             const uint32_t slot = slot_kind & kSlotMask, kind = slot_kind >> 30;
-            if (kind == kRayExt)
+            if (kind == kRayExt) {
                 st.hit_prim[slot] = tv.best_prim;
+                st.hit_slot[slot] = tv.best_slot;
+            }
             else if (kind == kRayShadow)
                 st.sh_prim[slot] = tv.best_prim;
             else
@@ -433,6 +435,7 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool va
     const D3 l_in = ld3(in.lx, in.ly, in.lz, ls), o_in = ld3(in.ox, in.oy, in.oz, ls);
     const D3 d_in = ld3(in.dx, in.dy, in.dz, ls), beta_in = ld3(in.bx, in.by, in.bz, ls);
     const int32_t hp_in = in.hit_prim[ls], sh_in = in.sh_prim[ls], pp_in = in.pr_prim[ls];
+    const uint32_t hs_in = in.hit_slot[ls];
     const D3 a_in = ld3(in.ax, in.ay, in.az, ls), q_in = ld3(in.qx, in.qy, in.qz, ls), k_in = ld3(in.kx, in.ky, in.kz, ls);
     a.rng = in.rng[ls];
     a.orig = in.orig[ls];
@@ -488,11 +491,11 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool va
         a.d = d_in;
         a.beta = beta_in;
         is_some = hp >= 0;
-        if (is_some) is_some = prim_intersects(sc, hp, a.o, a.d, kSmall, kInf, a.rec);
+        if (is_some) is_some = hit_record(sc, hp, hs_in, a.o, a.d, kSmall, kInf, a.rec);
         RT_PROF(1)
         if (a.bounces == 0 || a.spec) {  // integrator.rs:396-411 (Q18)
             if (is_some) {
-                const int32_t li = sc.prims[a.rec.prim].light_index;
+                const int32_t li = a.rec.light;
                 if (li >= 0) a.L = a.L + cmul(light_l(sc.lights[li], a.rec.n, -a.d), a.beta);
             } else if (FULL && sc.env.light >= 0) {
                 // escaped: every light adds le(ray), black for all but the infinite one (light.rs:499-512)
@@ -757,7 +760,7 @@ __global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathS
         if (fl & kHasProbe)
             in.pr_prim[slot] = closest_hit<false>(sc, o, ld3(in.pdx, in.pdy, in.pdz, slot), kSmall, kInf, t, ts, &tc);
         if (!(fl & kFoldOnly))
-            in.hit_prim[slot] = closest_hit<false>(sc, o, ld3(in.dx, in.dy, in.dz, slot), kSmall, kInf, t, ts, &tc);
+            in.hit_prim[slot] = closest_hit<false>(sc, o, ld3(in.dx, in.dy, in.dz, slot), kSmall, kInf, t, ts, &tc, &in.hit_slot[slot]);
         ShadeA a;
         RT_PROF_DECL
         shade_a<FULL>(sc, in, slot, true, max_depth, a RT_PROF_PASS);

@@ -22,13 +22,19 @@ struct DevNode {
 static_assert(sizeof(DevNode) == 128, "DevNode must be 128 bytes");
 constexpr int32_t kNoChild = INT32_MIN;
 constexpr uint32_t kLeafOther = 0x80000000u;  // leaf entry is a sphere/rect, not a triangle
-constexpr uint32_t kLeafCodeOther = 1u << 30;  // leaf code flag: the leaf holds one sphere/rect (they never share a leaf)
+constexpr uint32_t kLeafCodeOther = 1u << 30;
+constexpr uint32_t kMetaHasNormals = 1u << 30, kMetaFlip = 1u << 31, kMetaMatMask = 0x3fffffffu;  // leaf code flag: the leaf holds one sphere/rect (they never share a leaf)
 constexpr int kMaxLeafPrims = 4;     // what a leaf code can hold
 // What the builders aim for.  One primitive per leaf: the parent's f32 test of the child box then culls each
 // triangle on its own, before the f64 own-box + triangle test that a leaf step costs (measured on C3: trace
 // -19 %, C2: -10 % against leaves of up to 4).
 constexpr int kLeafTargetPrims = 1;
 constexpr int kMaxBvhDepth = 24;  // of the 4-wide tree; traversal stack: 16 LDS + 58 private entries (geom.h)
+
+struct LeafMeta {
+    uint32_t mat_flags;  // mat_index | kMetaHasNormals | kMetaFlip
+    int32_t light;       // light_index of the primitive
+};
 
 struct DevMesh {
     const double* p;
@@ -56,6 +62,10 @@ struct DevScene {
     const DevNode* nodes;
     const uint32_t* leaf_prim;  // leaf order -> prim index | kLeafOther
     const double* leaf_tri;     // leaf order -> 9 doubles p0,p1,p2 (triangles), 72 B
+    // Shading side of a triangle's leaf slot, so that rebuilding the winner's hit record needs one dependent
+    // fetch (slot -> vertices + normals + meta) instead of five (prim -> mesh -> indices -> positions/normals):
+    const double* leaf_nrm;     // leaf order -> 9 doubles n0,n1,n2 (null: no mesh has normals)
+    const LeafMeta* leaf_meta;  // leaf order -> {mat_index | kMetaHasNormals | kMetaFlip, light_index}
     const rt_primitive* prims;  // original order (shading + sphere/rect tests)
     const DevMesh* meshes;
     const rt_xform* xforms;
@@ -82,6 +92,7 @@ struct PathState {
     double *kx, *ky, *kz;     // beta at the vertex that produced the pending terms
     uint64_t* rng;
     int32_t* hit_prim;        // result of the extension ray
+    uint32_t* hit_slot;       // leaf slot of that hit (| kLeafOther for a sphere / rect)
     int32_t* sh_prim;         // closest prim along the shadow ray (Q13)
     int32_t* pr_prim;         // closest prim along the probe ray
     uint32_t* flags;
