@@ -385,7 +385,24 @@ int rt_scene_commit_ex(rt_scene* s, uint32_t flags) {
     }
     if ((rc = upload(s, dm.data(), dm.size(), &d.meshes)) != RT_OK) return rc;
     if ((rc = upload(s, s->xforms.data(), s->xforms.size(), &d.xforms)) != RT_OK) return rc;
-    if ((rc = upload(s, s->mats.data(), s->mats.size(), &d.mats)) != RT_OK) return rc;
+    {   // materials with their texture references resolved (scene_dev.h: DevMat)
+        std::vector<DevMat> dmats(s->mats.size());
+        for (size_t i = 0; i < dmats.size(); i++) {
+            DevMat& dm = dmats[i];
+            std::memset(&dm, 0, sizeof(dm));
+            dm.m = s->mats[i];
+            for (int k = 0; k < 5; k++) dm.tex[k] = dm.m.tex[k];
+            if (dm.m.kind == RT_MAT_METAL)
+                for (int k = 3; k <= 4; k++)
+                    if (dm.tex[k] == RT_NO_TEXTURE) dm.tex[k] = dm.tex[2];
+            for (int k = 0; k < 5; k++) {
+                if (dm.tex[k] >= s->texs.size() || s->texs[dm.tex[k]].kind != RT_TEX_SOLID) continue;
+                dm.solid_mask |= 1u << k;
+                for (int c = 0; c < 3; c++) dm.col[k][c] = s->texs[dm.tex[k]].color[c];
+            }
+        }
+        if ((rc = upload(s, dmats.data(), dmats.size(), &d.mats)) != RT_OK) return rc;
+    }
     {   // textures: HDR texels go to HBM first, the records point at the device copies
         std::vector<rt_texture> dtex = s->texs;
         for (size_t i = 0; i < dtex.size(); i++) {

@@ -31,6 +31,15 @@ constexpr int kMaxLeafPrims = 4;     // what a leaf code can hold
 constexpr int kLeafTargetPrims = 1;
 constexpr int kMaxBvhDepth = 24;  // of the 4-wide tree; traversal stack: 16 LDS + 58 private entries (geom.h)
 
+// rt_material with its texture references resolved at commit: a solid-colour texture (the usual case) is
+// embedded, so compute_scattering reads material -> colour in one fetch instead of material -> texture record.
+struct DevMat {
+    rt_material m;
+    uint32_t tex[5];      // m.tex with Metal's RT_NO_TEXTURE fallbacks applied (material.rs:193-208)
+    uint32_t solid_mask;  // bit k: tex[k] is a solid colour, col[k] holds it
+    double col[5][3];
+};
+
 struct LeafMeta {
     uint32_t mat_flags;  // mat_index | kMetaHasNormals | kMetaFlip
     int32_t light;       // light_index of the primitive
@@ -69,7 +78,7 @@ struct DevScene {
     const rt_primitive* prims;  // original order (shading + sphere/rect tests)
     const DevMesh* meshes;
     const rt_xform* xforms;
-    const rt_material* mats;
+    const DevMat* mats;
     const rt_texture* texs;
     const rt_light* lights;
     uint32_t n_prims, n_lights, n_nodes, mesh_has_uv;  // mesh_has_uv: any mesh carries uvs

@@ -506,22 +506,29 @@ RTD Lobe make_microfacet(D3 c, double ax, double ay) {  // + microfacet.rs:340-3
     return l;
 }
 
+// texture k of a material: the embedded colour when the texture is a solid one (same value as Texture::value)
+RTD D3 mat_tex(const DevScene& sc, const DevMat& dm, int k, double u, double v) {
+    if (dm.solid_mask & (1u << k)) return d3(dm.col[k][0], dm.col[k][1], dm.col[k][2]);
+    return texture_value(sc, dm.tex[k], u, v);
+}
+
 // material.rs:80-244 with mode = RADIANCE, allow_lobes = true
 template <bool FULL>
 RTD void compute_scattering(const DevScene& sc, const HitRec& h, Bsdf& b) {
-    const rt_material& m = sc.mats[h.mat];
+    const DevMat& dm = sc.mats[h.mat];
+    const rt_material& m = dm.m;
     b.n = 0;
     b.lobes[0] = lobe_zero();
     b.lobes[1] = lobe_zero();
     if (m.kind == RT_MAT_MATTE) {
-        D3 color = texture_value(sc, m.tex[0], h.u, h.v);
+        D3 color = mat_tex(sc, dm, 0, h.u, h.v);
         if (!is_black(color)) {
             bsdf_init(b, h);
             b.lobes[0] = make_lambert(color);
             b.n = 1;
         }
     } else if (m.kind == RT_MAT_PLASTIC) {
-        D3 color = texture_value(sc, m.tex[0], h.u, h.v);
+        D3 color = mat_tex(sc, dm, 0, h.u, h.v);
         bool inited = false;
         if (!is_black(color)) {
             bsdf_init(b, h);
@@ -529,7 +536,7 @@ RTD void compute_scattering(const DevScene& sc, const HitRec& h, Bsdf& b) {
             b.lobes[0] = make_lambert(color);
             b.n = 1;
         }
-        D3 spec = texture_value(sc, m.tex[1], h.u, h.v);
+        D3 spec = mat_tex(sc, dm, 1, h.u, h.v);
         if (!is_black(spec)) {
             if (!inited) bsdf_init(b, h);
             double rough = m.f[0];
@@ -545,8 +552,8 @@ RTD void compute_scattering(const DevScene& sc, const HitRec& h, Bsdf& b) {
             b.n++;
         }
     } else if (m.kind == RT_MAT_GLASS) {
-        D3 r = texture_value(sc, m.tex[0], h.u, h.v);
-        D3 t = texture_value(sc, m.tex[1], h.u, h.v);
+        D3 r = mat_tex(sc, dm, 0, h.u, h.v);
+        D3 t = mat_tex(sc, dm, 1, h.u, h.v);
         bsdf_init(b, h);
         if (!(is_black(r) && is_black(t))) {
             double urough = m.f[0], vrough = m.f[1];
@@ -590,19 +597,19 @@ RTD void compute_scattering(const DevScene& sc, const HitRec& h, Bsdf& b) {
         }
     } else if (m.kind == RT_MAT_METAL) {
         bsdf_init(b, h);
-        D3 ur = texture_value(sc, m.tex[3] == RT_NO_TEXTURE ? m.tex[2] : m.tex[3], h.u, h.v);
-        D3 vr = texture_value(sc, m.tex[4] == RT_NO_TEXTURE ? m.tex[2] : m.tex[4], h.u, h.v);
+        D3 ur = mat_tex(sc, dm, 3, h.u, h.v);
+        D3 vr = mat_tex(sc, dm, 4, h.u, h.v);
         double ua = m.remap_roughness ? tr_roughness_to_alpha(ur.x) : ur.x;
         double va = m.remap_roughness ? tr_roughness_to_alpha(vr.x) : vr.x;
         Lobe l = make_microfacet(white(), ua, va);
         l.fresnel = FR_CONDUCTOR;
-        l.t = texture_value(sc, m.tex[0], h.u, h.v);
-        l.k = texture_value(sc, m.tex[1], h.u, h.v);
+        l.t = mat_tex(sc, dm, 0, h.u, h.v);
+        l.k = mat_tex(sc, dm, 1, h.u, h.v);
         b.lobes[0] = l;
         b.n = 1;
     } else if (m.kind == RT_MAT_MIRROR) {
         bsdf_init(b, h);
-        D3 color = texture_value(sc, m.tex[0], h.u, h.v);
+        D3 color = mat_tex(sc, dm, 0, h.u, h.v);
         if (!is_black(color)) {
             Lobe l = lobe_zero();
             l.kind = LOBE_SPECULAR_REFL;
