@@ -11,6 +11,8 @@
 #include "bvh_build.h"
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -61,11 +63,24 @@ struct BinNode {
     bool is_leaf = false;
 };
 
+struct Deferred {
+    size_t b, e;
+    uint32_t depth;
+    int32_t node;  // placeholder in the parent builder's `bin`
+};
+
 struct Builder {
     const rt_primitive* prims;
-    std::vector<uint32_t> order;  // primitive ids, partitioned in place
-    std::vector<double> cx, cy, cz;
+    std::vector<uint32_t> order_store;  // primitive ids, partitioned in place (owned by the top builder)
+    std::vector<double> cx_store, cy_store, cz_store;
+    uint32_t* order = nullptr;
+    const double *cx = nullptr, *cy = nullptr, *cz = nullptr;
     std::vector<BinNode> bin;
+    // parallel build: subtrees of at least `defer_min` primitives at depth >= `defer_depth` are left as
+    // placeholders for worker threads (each builds into its own `bin`; the ranges of `order` are disjoint)
+    uint32_t defer_depth = 0xffffffffu;
+    size_t defer_min = 0;
+    std::vector<Deferred> deferred;
     uint32_t sah_depth = 32;  // experiment knobs: RT_BVH_SAH_DEPTH, RT_BVH_BINS
     int n_bins = 16;
     size_t max_leaf = (size_t)kLeafTargetPrims;  // RT_BVH_LEAF
@@ -74,18 +89,24 @@ struct Builder {
         if (const char* e = getenv("RT_BVH_SAH_DEPTH")) sah_depth = (uint32_t)std::max(1, atoi(e));
         if (const char* e = getenv("RT_BVH_BINS")) n_bins = std::min(64, std::max(2, atoi(e)));
         if (const char* e = getenv("RT_BVH_LEAF")) max_leaf = (size_t)std::min(kMaxLeafPrims, std::max(1, atoi(e)));
-        order.resize(n);
-        cx.resize(n);
-        cy.resize(n);
-        cz.resize(n);
+        order_store.resize(n);
+        cx_store.resize(n);
+        cy_store.resize(n);
+        cz_store.resize(n);
         for (size_t i = 0; i < n; i++) {
-            order[i] = (uint32_t)i;
-            cx[i] = 0.5 * (p[i].bbox_min[0] + p[i].bbox_max[0]);
-            cy[i] = 0.5 * (p[i].bbox_min[1] + p[i].bbox_max[1]);
-            cz[i] = 0.5 * (p[i].bbox_min[2] + p[i].bbox_max[2]);
+            order_store[i] = (uint32_t)i;
+            cx_store[i] = 0.5 * (p[i].bbox_min[0] + p[i].bbox_max[0]);
+            cy_store[i] = 0.5 * (p[i].bbox_min[1] + p[i].bbox_max[1]);
+            cz_store[i] = 0.5 * (p[i].bbox_min[2] + p[i].bbox_max[2]);
         }
-        bin.reserve(n);
+        order = order_store.data();
+        cx = cx_store.data();
+        cy = cy_store.data();
+        cz = cz_store.data();
     }
+    // a worker's view of the same arrays
+    Builder(const Builder& top, int) : prims(top.prims), order(top.order), cx(top.cx), cy(top.cy), cz(top.cz),
+                                       sah_depth(top.sah_depth), n_bins(top.n_bins), max_leaf(top.max_leaf) {}
     double centroid(uint32_t id, int axis) const { return axis == 0 ? cx[id] : (axis == 1 ? cy[id] : cz[id]); }
 
     Box bounds(size_t b, size_t e) const {
@@ -109,6 +130,10 @@ struct Builder {
         if (n <= max_leaf && (n == 1 || !any_other)) {
             bin[me].is_leaf = true;
             bin[me].leaf_ref = -1 - (int32_t)((uint32_t)(b * 8 + (n - 1)) | (any_other ? kLeafCodeOther : 0u));
+            return me;
+        }
+        if (depth >= defer_depth && n >= defer_min) {  // a worker thread builds this subtree
+            deferred.push_back(Deferred{b, e, depth, me});
             return me;
         }
         // centroid bounds
@@ -174,12 +199,12 @@ struct Builder {
             if (best_axis >= 0) {
                 double ext = cmx[best_axis] - cmn[best_axis];
                 double scale = (double)NB / ext;
-                auto it = std::partition(order.begin() + b, order.begin() + e, [&](uint32_t id) {
+                auto it = std::partition(order + b, order + e, [&](uint32_t id) {
                     int k = (int)((centroid(id, best_axis) - cmn[best_axis]) * scale);
                     k = std::min(std::max(k, 0), NB - 1);
                     return k <= best_bin;
                 });
-                mid = (size_t)(it - order.begin());
+                mid = (size_t)(it - order);
                 split_done = mid > b && mid < e;
             }
         }
@@ -192,7 +217,7 @@ struct Builder {
                     axis = a;
                 }
             mid = b + n / 2;
-            std::nth_element(order.begin() + b, order.begin() + mid, order.begin() + e, [&](uint32_t x, uint32_t y) {
+            std::nth_element(order + b, order + mid, order + e, [&](uint32_t x, uint32_t y) {
                 double a_ = centroid(x, axis), b_ = centroid(y, axis);
                 return a_ < b_ || (a_ == b_ && x < y);
             });
@@ -271,7 +296,48 @@ static void build_once(const rt_primitive* prims, size_t n, uint32_t sah_depth_c
     out.depth = 0;
     Builder bd(prims, n);
     bd.sah_depth = std::min(bd.sah_depth, sah_depth_cap);
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (hw > 1 && n >= 65536) {
+        bd.defer_depth = 5;
+        bd.defer_min = 2048;
+    }
     const int32_t root = bd.build(0, n, 0);
+    if (!bd.deferred.empty()) {
+        // workers: one private Builder per deferred subtree, same splits as the serial build would make
+        std::vector<Builder> subs;
+        subs.reserve(bd.deferred.size());
+        for (size_t i = 0; i < bd.deferred.size(); i++) subs.emplace_back(bd, 0);
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (size_t i; (i = next.fetch_add(1)) < bd.deferred.size();) {
+                const Deferred& d = bd.deferred[i];
+                subs[i].bin.reserve(2 * (d.e - d.b));
+                subs[i].build(d.b, d.e, d.depth);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < hw; t++) pool.emplace_back(work);
+        work();
+        for (auto& t : pool) t.join();
+        // splice: a sub-builder's node 0 replaces the placeholder, the rest is appended
+        for (size_t i = 0; i < bd.deferred.size(); i++) {
+            const int32_t hole = bd.deferred[i].node;
+            const int32_t base = (int32_t)bd.bin.size() - 1;
+            auto remap = [&](int32_t c) { return c < 0 ? c : (c == 0 ? hole : base + c); };
+            const std::vector<BinNode>& sb = subs[i].bin;
+            for (size_t k = 0; k < sb.size(); k++) {
+                BinNode nd = sb[k];
+                if (!nd.is_leaf) {
+                    nd.left = remap(nd.left);
+                    nd.right = remap(nd.right);
+                }
+                if (k == 0)
+                    bd.bin[hole] = nd;
+                else
+                    bd.bin.push_back(nd);
+            }
+        }
+    }
     out.nodes.reserve(bd.bin.size() / 2 + 2);
     if (bd.bin[root].is_leaf) {
         // the whole scene fits one leaf: wrap it so that node 0 is always internal
@@ -287,7 +353,7 @@ static void build_once(const rt_primitive* prims, size_t n, uint32_t sah_depth_c
         col.emit(root, 0);
         out.depth = col.max_depth;
     }
-    out.order = std::move(bd.order);
+    out.order = std::move(bd.order_store);
 }
 
 void build_bvh(const rt_primitive* prims, size_t n, BvhOut& out) {
