@@ -96,7 +96,7 @@ struct rt_scene {
     std::vector<std::vector<uint8_t>> hdr;  // texel copies of the RT_TEX_HDR textures (texs[i].rgbe points here)
     std::vector<rt_light> lights;
     bool committed = false;
-    bool full_shading = false;  // the scene needs the kernels compiled with the row-f4 features (rough glass, infinite light)
+    int shade_variant = 0;  // index into kFeatVariants: the smallest shading-kernel instance that covers the scene
     // device
     std::vector<void*> allocs;
     DevScene dev{};
@@ -418,9 +418,13 @@ int rt_scene_commit_ex(rt_scene* s, uint32_t flags) {
     }
     if ((rc = upload(s, s->lights.data(), s->lights.size(), &d.lights)) != RT_OK) return rc;
     d.env.light = -1;
-    s->full_shading = false;
-    for (const rt_material& m : s->mats)
-        if (m.kind == RT_MAT_GLASS && (m.f[0] != 0.0 || m.f[1] != 0.0)) s->full_shading = true;
+    int need = 0;  // shading.h: kFeat*
+    for (const rt_material& m : s->mats) {
+        if (m.kind == RT_MAT_PLASTIC) need |= kFeatMicro | kFeatTwo;
+        if (m.kind == RT_MAT_METAL) need |= kFeatMicro;
+        if (m.kind == RT_MAT_MIRROR) need |= kFeatSpec;
+        if (m.kind == RT_MAT_GLASS) need |= (m.f[0] != 0.0 || m.f[1] != 0.0) ? kFeatFull : kFeatSpec;
+    }
     for (size_t i = 0; i < s->lights.size(); i++) {
         if (s->lights[i].kind != RT_LIGHT_INFINITE) continue;
         // Light::make_infinite_light's Distribution2D (light.rs:608-638), rebuilt from the texels
@@ -434,8 +438,12 @@ int rt_scene_commit_ex(rt_scene* s, uint32_t flags) {
         d.env.nu = ed.nu;
         d.env.nv = ed.nv;
         d.env.light = (int32_t)i;
-        s->full_shading = true;
+        need |= kFeatFull;
     }
+    s->shade_variant = 3;
+    for (int v = 3; v >= 0; v--)
+        if ((need & ~kFeatVariants[v]) == 0) s->shade_variant = v;
+    if (const char* e = getenv("RT_SHADE_VARIANT")) s->shade_variant = std::max(s->shade_variant, std::min(3, atoi(e)));
     uint64_t n_tri = 0;
     uint32_t depth = 0;
     bool any_normals = false;
@@ -577,6 +585,27 @@ static int lane_fail(Lane& ln, int code, const char* fmt, ...) {
         }                                                                                                   \
     } while (0)
 
+typedef void (*ShadeKernel)(DevScene, PathState, PathState, Ctl*, uint32_t, uint32_t, uint32_t*, double*, double*, double*,
+                            DevStats*);
+typedef void (*TailKernel)(DevScene, PathState, PathState, const Ctl*, uint32_t, uint32_t, double*, double*, double*,
+                           DevStats*);
+static ShadeKernel shade_kernel(int v) {
+    switch (v) {
+        case 0: return k_shade<kFeatVariants[0]>;
+        case 1: return k_shade<kFeatVariants[1]>;
+        case 2: return k_shade<kFeatVariants[2]>;
+        default: return k_shade<kFeatVariants[3]>;
+    }
+}
+static TailKernel tail_kernel(int v) {
+    switch (v) {
+        case 0: return k_tail<kFeatVariants[0]>;
+        case 1: return k_tail<kFeatVariants[1]>;
+        case 2: return k_tail<kFeatVariants[2]>;
+        default: return k_tail<kFeatVariants[3]>;
+    }
+}
+
 // One lane's share of a batch: keep `pool` paths alive, topping up from the shared batch counter,
 // until the batch is exhausted and this lane's paths have all retired.
 static int run_lane(RenderJob& job, int lane_id) {
@@ -625,7 +654,7 @@ static int run_lane(RenderJob& job, int lane_id) {
                 if (live <= c->tail_paths) {
                     // few paths left: one fused launch finishes them (k_tail) instead of ~2 launches per bounce
                     // that are each as slow as their single longest ray
-                    hipLaunchKernelGGL(job.s->full_shading ? k_tail<true> : k_tail<false>, dim3((live + 255) / 256), dim3(256), 0, stream, job.s->dev, ln.st[0],
+                    hipLaunchKernelGGL(tail_kernel(job.s->shade_variant), dim3((live + 255) / 256), dim3(256), 0, stream, job.s->dev, ln.st[0],
                                        ln.st[1], ln.ctl, (uint32_t)it, cfg->max_depth, c->lf[0], c->lf[1], c->lf[2],
                                        c->stats);
                     break;
@@ -664,7 +693,7 @@ static int run_lane(RenderJob& job, int lane_id) {
             ln.trace_ev.emplace_back(a, b);
         }
         ln.trace_launches++;
-        hipLaunchKernelGGL(job.s->full_shading ? k_shade<true> : k_shade<false>, dim3(shade_blocks), dim3(256), 0, stream, job.s->dev, ln.st[it & 1],
+        hipLaunchKernelGGL(shade_kernel(job.s->shade_variant), dim3(shade_blocks), dim3(256), 0, stream, job.s->dev, ln.st[it & 1],
                            ln.st[(it + 1) & 1], ln.ctl, (uint32_t)it, cfg->max_depth, ln.queue[(it + 1) & 1], c->lf[0],
                            c->lf[1], c->lf[2], c->stats);
     }

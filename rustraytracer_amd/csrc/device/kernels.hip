@@ -426,7 +426,7 @@ struct ShadeA {
     bool live, spec, will_shade;
 };
 
-template <bool FULL>
+template <int FEAT>
 RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool valid, uint32_t max_depth, ShadeA& a RT_PROF_ARG) {
     // Every field of the slot this function may need is fetched up front, unconditionally: the loads are
     // independent and coalesced, so they cost one memory latency instead of one per branch level below.
@@ -451,7 +451,7 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool va
         if (fl & (kHasShadow | kHasProbe)) {
             const uint32_t light_idx = fl >> kLightShift;
             const rt_light& lt = sc.lights[light_idx];
-            const bool infinite = FULL && lt.kind == RT_LIGHT_INFINITE;
+            const bool infinite = ((FEAT & kFeatFull) != 0) && lt.kind == RT_LIGHT_INFINITE;
             D3 ld = black();
             if (fl & kHasShadow) {
                 // Visibility::unoccluded(infinite): an area light must be the closest hit, the environment needs a miss
@@ -497,7 +497,7 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool va
             if (is_some) {
                 const int32_t li = a.rec.light;
                 if (li >= 0) a.L = a.L + cmul(light_l(sc.lights[li], a.rec.n, -a.d), a.beta);
-            } else if (FULL && sc.env.light >= 0) {
+            } else if (((FEAT & kFeatFull) != 0) && sc.env.light >= 0) {
                 // escaped: every light adds le(ray), black for all but the infinite one (light.rs:499-512)
                 a.L = a.L + cmul(infinite_le(sc, sc.lights[sc.env.light], a.d), a.beta);
             }
@@ -512,7 +512,7 @@ struct ShadeOut {
 };
 
 // Precondition: a.will_shade.  `os` = slot of `out` reserved for this vertex.
-template <bool FULL>
+template <int FEAT>
 RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& out, uint32_t slot, uint32_t os,
                      ShadeA& a RT_PROF_ARG) {
     const HitRec& rec = a.rec;
@@ -521,7 +521,7 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
     bool spec = a.spec;
     uint64_t rng = a.rng;
     Bsdf bsdf;
-    compute_scattering<FULL>(sc, rec, bsdf);
+    compute_scattering<FEAT>(sc, rec, bsdf);
     RT_PROF(3)
     bool has_sh = false, has_pr = false;
     uint32_t light_num = 0;
@@ -533,7 +533,7 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
         const double ul0 = rng_next(rng), ul1 = rng_next(rng);
         const double us0 = rng_next(rng), us1 = rng_next(rng);
         const rt_light& lt = sc.lights[light_num];
-        const bool infinite = FULL && lt.kind == RT_LIGHT_INFINITE;
+        const bool infinite = ((FEAT & kFeatFull) != 0) && lt.kind == RT_LIGHT_INFINITE;
         const rt_primitive& lp = sc.prims[infinite ? 0u : lt.prim_index];
         const uint32_t nsf = RT_BSDF_ALL - RT_BSDF_SPECULAR;
         const D3 ltcolor = d3(lt.color[0], lt.color[1], lt.color[2]);
@@ -561,8 +561,8 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
             }
         }
         if (light_pdf > 0.0 && !is_black(color)) {
-            const D3 f = bsdf_f<FULL>(bsdf, rec.wo, wi, nsf) * absd(dot(wi, rec.sh_n));
-            const double scattering_pdf = bsdf_pdf<FULL>(bsdf, rec.wo, wi, nsf);
+            const D3 f = bsdf_f<FEAT>(bsdf, rec.wo, wi, nsf) * absd(dot(wi, rec.sh_n));
+            const double scattering_pdf = bsdf_pdf<FEAT>(bsdf, rec.wo, wi, nsf);
             if (!is_black(f)) {
                 has_sh = true;
                 const double weight = power_heuristic(1, light_pdf, 1, scattering_pdf);
@@ -575,7 +575,7 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
             D3 f2, wi2;
             double spdf;
             uint32_t sampled;
-            bsdf_sample_f<FULL>(bsdf, rec.wo, us0, us1, nsf, rng, f2, wi2, spdf, sampled);
+            bsdf_sample_f<FEAT>(bsdf, rec.wo, us0, us1, nsf, rng, f2, wi2, spdf, sampled);
             f2 = f2 * absd(dot(wi2, rec.sh_n));
             if (!is_black(f2) && spdf > 0.0) {
                 double weight = 1.0;
@@ -605,7 +605,7 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
     D3 f, wi;
     double pdf;
     uint32_t sflags;
-    bsdf_sample_f<FULL>(bsdf, wo, u0, u1, RT_BSDF_ALL, rng, f, wi, pdf, sflags);
+    bsdf_sample_f<FEAT>(bsdf, wo, u0, u1, RT_BSDF_ALL, rng, f, wi, pdf, sflags);
     bool cont = !(is_black(f) || pdf == 0.0);
     if (cont) {
         beta = cmul(beta, f) * (absd(dot(wi, rec.sh_n)) / pdf);
@@ -646,8 +646,8 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 2
 #endif
-template <bool FULL>
-__global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_shade(DevScene sc, PathState in, PathState out, Ctl* ctl, uint32_t it_abs,
+template <int FEAT>
+__global__ __launch_bounds__(256, FEAT == 0 ? 3 : RT_SHADE_WAVES) void k_shade(DevScene sc, PathState in, PathState out, Ctl* ctl, uint32_t it_abs,
                                                uint32_t max_depth, uint32_t* queue_out, double* lfx, double* lfy,
                                                double* lfz, DevStats* stats) {
     const uint32_t it = it_abs % kRing, itn = (it_abs + 1) % kRing;
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_shade(DevScene sc, Path
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     ShadeA a;
     RT_PROF_DECL
-    shade_a<FULL>(sc, in, slot, slot < n_active, max_depth, a RT_PROF_PASS);
+    shade_a<FEAT>(sc, in, slot, slot < n_active, max_depth, a RT_PROF_PASS);
     // a vertex that will be shaded gets its output slot now (dense, block-contiguous); if the path
     // then ends without pending light terms the slot is marked dead and skipped next bounce
     uint32_t os;
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_shade(DevScene sc, Path
     }
     RT_PROF(8)
     ShadeOut r{false, false, false, false};
-    if (a.will_shade) r = shade_b<FULL>(sc, in, out, slot, os, a RT_PROF_PASS);
+    if (a.will_shade) r = shade_b<FEAT>(sc, in, out, slot, os, a RT_PROF_PASS);
     if (a.live && !r.keep) {  // retired: its radiance goes to the film staging slot of (pixel, sample)
         const uint32_t og = a.orig;
         lfx[og] = a.L.x;
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_shade(DevScene sc, Path
 // finishes those paths in ONE launch: each lane traces its own pending rays (shadow, probe, extension)
 // with the same closest_hit and shades with the same shade_a / shade_b, ping-ponging its slot between
 // the two state buffers, until its path retires.  Same arithmetic, same counters, no queues.
-template <bool FULL>
+template <int FEAT>
 __global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathState buf1, const Ctl* ctl,
                                              uint32_t it_abs, uint32_t max_depth, double* lfx, double* lfy,
                                              double* lfz, DevStats* stats) {
@@ -763,10 +763,10 @@ __global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathS
             in.hit_prim[slot] = closest_hit<false>(sc, o, ld3(in.dx, in.dy, in.dz, slot), kSmall, kInf, t, ts, &tc, &in.hit_slot[slot]);
         ShadeA a;
         RT_PROF_DECL
-        shade_a<FULL>(sc, in, slot, true, max_depth, a RT_PROF_PASS);
+        shade_a<FEAT>(sc, in, slot, true, max_depth, a RT_PROF_PASS);
         ShadeOut r{false, false, false, false};
         if (a.will_shade) {
-            r = shade_b<FULL>(sc, in, out, slot, slot, a RT_PROF_PASS);
+            r = shade_b<FEAT>(sc, in, out, slot, slot, a RT_PROF_PASS);
             n_v++;
         }
         n_r1 += r.emit_ext ? 1u : 0u;

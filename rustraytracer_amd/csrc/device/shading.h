@@ -250,12 +250,20 @@ RTD double tr_roughness_to_alpha(double roughness) {  // microfacet.rs:442-446
 
 RTD bool matches_flags(uint32_t flag, uint32_t other) { return (flag & other) == flag; }
 
-// FULL: the scene uses the next-row f4 features (MicrofacetTransmission lobes, an infinite light); scenes that
-// do not run the kernels compiled without them (k_shade<false>), which keeps their register budget.
-template <bool FULL>
+// FEAT: which lobes / features a kernel instance is compiled with.  rt_scene_commit picks the smallest
+// instance that covers the scene's materials and lights, so a Lambertian scene does not pay (in registers,
+// hence occupancy of the latency-bound shading kernel, and in code) for microfacet, specular and two-lobe
+// materials it does not contain, nor any scene for the row-f4 features it does not use.
+constexpr int kFeatMicro = 1;  // microfacet lobes: Plastic, Metal (and rough Glass)
+constexpr int kFeatSpec = 2;   // perfectly specular lobes: smooth Glass, Mirror
+constexpr int kFeatTwo = 4;    // two-lobe materials: Plastic (and rough Glass)
+constexpr int kFeatFull = 8;   // row f4: MicrofacetTransmission (rough Glass), the infinite light
+constexpr int kFeatVariants[4] = {0, kFeatMicro | kFeatSpec, kFeatMicro | kFeatSpec | kFeatTwo,
+                                  kFeatMicro | kFeatSpec | kFeatTwo | kFeatFull};
+template <int FEAT>
 RTD D3 bxdf_f(const Lobe& l, D3 wo, D3 wi) {
     if (l.kind == LOBE_LAMBERT) return l.color * kInvPi;
-    if (l.kind == LOBE_MICROFACET) {
+    if ((FEAT & kFeatMicro) && l.kind == LOBE_MICROFACET) {
         double cos_o = absd(wo.z), cos_i = absd(wi.z);
         D3 wh = wi + wo;
         if (cos_i == 0.0 || cos_o == 0.0) return black();
@@ -265,7 +273,7 @@ RTD D3 bxdf_f(const Lobe& l, D3 wo, D3 wi) {
         D3 comp1 = l.color * tr_d(l.alpha_x, l.alpha_y, wh) * tr_g(l.alpha_x, l.alpha_y, wo, wi);
         return cmul(comp1, f * (1.0 / (4.0 * cos_i * cos_o)));
     }
-    if (FULL && l.kind == LOBE_MICRO_TRANS) {  // bxdf.rs:393-441 (mode == RADIANCE); eta_a = p0, eta_b = p1
+    if (((FEAT & kFeatFull) != 0) && l.kind == LOBE_MICRO_TRANS) {  // bxdf.rs:393-441 (mode == RADIANCE); eta_a = p0, eta_b = p1
         if (same_hemisphere(wo, wi)) return black();
         const double cos_theta_o = wo.z, cos_theta_i = wi.z;
         if (cos_theta_i == 0.0 || cos_theta_o == 0.0) return black();
@@ -283,16 +291,16 @@ RTD D3 bxdf_f(const Lobe& l, D3 wo, D3 wi) {
     }
     return black();
 }
-template <bool FULL>
+template <int FEAT>
 RTD double bxdf_pdf(const Lobe& l, D3 wo, D3 wi) {
     if (l.kind == LOBE_LAMBERT || l.kind == LOBE_SPECULAR_REFL)
         return same_hemisphere(wo, wi) ? absd(wi.z) * kInvPi : 0.0;
-    if (l.kind == LOBE_MICROFACET) {
+    if ((FEAT & kFeatMicro) && l.kind == LOBE_MICROFACET) {
         if (!same_hemisphere(wo, wi)) return 0.0;
         D3 wh = normalize(wo + wi);
         return tr_pdf(l.alpha_x, l.alpha_y, wo, wh) / (4.0 * dot(wo, wh));
     }
-    if (FULL && l.kind == LOBE_MICRO_TRANS) {  // bxdf.rs:742-763
+    if (((FEAT & kFeatFull) != 0) && l.kind == LOBE_MICRO_TRANS) {  // bxdf.rs:742-763
         if (same_hemisphere(wo, wi)) return 0.0;
         const double eta = wo.z > 0.0 ? l.p1 / l.p0 : l.p0 / l.p1;
         const D3 wh = normalize(wo + wi * eta);
@@ -304,7 +312,7 @@ RTD double bxdf_pdf(const Lobe& l, D3 wo, D3 wi) {
     return 0.0;
 }
 // `rng` supplies default_sample_f's two entropy draws (bxdf.rs:815-827)
-template <bool FULL>
+template <int FEAT>
 RTD void bxdf_sample_f(const Lobe& l, D3 wo, double u0, double u1, uint64_t& rng, D3& f, D3& wi, double& pdf) {
     f = black();
     wi = black();
@@ -314,17 +322,17 @@ RTD void bxdf_sample_f(const Lobe& l, D3 wo, double u0, double u1, uint64_t& rng
         double r2 = rng_next(rng);
         wi = rand_cosine_dir(r1, r2);
         if (wo.z < 0.0) wi.z *= -1.0;
-        pdf = bxdf_pdf<FULL>(l, wo, wi);
-        f = bxdf_f<FULL>(l, wo, wi);
-    } else if (l.kind == LOBE_MICROFACET) {
+        pdf = bxdf_pdf<FEAT>(l, wo, wi);
+        f = bxdf_f<FEAT>(l, wo, wi);
+    } else if ((FEAT & kFeatMicro) && l.kind == LOBE_MICROFACET) {
         if (wo.z == 0.0) return;
         D3 wh = tr_sample_wh(l.alpha_x, l.alpha_y, wo, u0, u1);
         D3 w2 = reflect(wo, wh);  // Q14: the wo.wh < 0 early-out is a no-op (bxdf.rs:598-600)
         if (!same_hemisphere(wo, w2)) return;
         wi = w2;
         pdf = tr_pdf(l.alpha_x, l.alpha_y, wo, wh) / (4.0 * dot(wo, wh));
-        f = bxdf_f<FULL>(l, wo, wi);
-    } else if (l.kind == LOBE_FRESNEL_SPECULAR) {  // Q15
+        f = bxdf_f<FEAT>(l, wo, wi);
+    } else if ((FEAT & kFeatSpec) && l.kind == LOBE_FRESNEL_SPECULAR) {  // Q15
         double fr = fr_dielectric(wo.z / norm(wo), l.p0, l.p1);
         if (u0 < fr) {
             wi = d3(-wo.x, -wo.y, wo.z);
@@ -343,7 +351,7 @@ RTD void bxdf_sample_f(const Lobe& l, D3 wo, double u0, double u1, uint64_t& rng
             wi = dirv;
             pdf = 1.0 - fr;
         }
-    } else if (FULL && l.kind == LOBE_MICRO_TRANS) {  // bxdf.rs:608-638
+    } else if (((FEAT & kFeatFull) != 0) && l.kind == LOBE_MICRO_TRANS) {  // bxdf.rs:608-638
         if (wo.z == 0.0) return;
         const D3 wh = tr_sample_wh(l.alpha_x, l.alpha_y, wo, u0, u1);
         if (dot(wo, wh) < 0.0) return;
@@ -351,9 +359,9 @@ RTD void bxdf_sample_f(const Lobe& l, D3 wo, double u0, double u1, uint64_t& rng
         D3 t;
         if (!refract(wo, wh, eta, t)) return;
         wi = t;
-        pdf = bxdf_pdf<FULL>(l, wo, wi);
-        f = bxdf_f<FULL>(l, wo, wi);
-    } else {  // LOBE_SPECULAR_REFL, bxdf.rs:543-552
+        pdf = bxdf_pdf<FEAT>(l, wo, wi);
+        f = bxdf_f<FEAT>(l, wo, wi);
+    } else if (FEAT & kFeatSpec) {  // LOBE_SPECULAR_REFL, bxdf.rs:543-552
         wi = d3(-wo.x, -wo.y, wo.z);
         f = cmul(l.color, fresnel_evaluate(l, wi.z));
         pdf = 1.0;
@@ -362,10 +370,11 @@ RTD void bxdf_sample_f(const Lobe& l, D3 wo, double u0, double u1, uint64_t& rng
 
 // The lobe array is only ever indexed with compile-time constants (or through pick_lobe's
 // field-wise select) so that it lives in VGPRs; a run-time index would push it to scratch.
+template <int FEAT>
 RTD Lobe pick_lobe(const Bsdf& b, int i) {
     const Lobe& a = b.lobes[0];
     const Lobe& c = b.lobes[1];
-    if (i == 0) return a;
+    if (!(FEAT & kFeatTwo) || i == 0) return a;
     return c;
 }
 
@@ -374,49 +383,50 @@ RTD D3 l2w(const Bsdf& b, D3 v) {
     return d3(b.ss.x * v.x + b.ts.x * v.y + b.ns.x * v.z, b.ss.y * v.x + b.ts.y * v.y + b.ns.y * v.z,
               b.ss.z * v.x + b.ts.z * v.y + b.ns.z * v.z);
 }
+template <int FEAT>
 RTD int num_components(const Bsdf& b, uint32_t flags) {
     int c = 0;
     if (b.n > 0 && matches_flags(b.lobes[0].type, flags)) c++;
-    if (b.n > 1 && matches_flags(b.lobes[1].type, flags)) c++;
+    if ((FEAT & kFeatTwo) && b.n > 1 && matches_flags(b.lobes[1].type, flags)) c++;
     return c;
 }
-template <bool FULL>
+template <int FEAT>
 RTD D3 bsdf_f(const Bsdf& b, D3 wow, D3 wiw, uint32_t flags) {  // bsdf.rs:83-98 (Q10)
     D3 wi = w2l(b, wiw), wo = w2l(b, wow);
     bool refl = dot(wiw, b.ng) * dot(wow, b.ng) > 0.0;
     D3 f = black();
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < ((FEAT & kFeatTwo) ? 2 : 1); i++) {
         if (i >= b.n) break;
         const Lobe& l = b.lobes[i];
         if ((matches_flags(l.type, flags) && (refl && (l.type & RT_BSDF_REFLECTION) > 0)) ||
             (!refl && (l.type & RT_BSDF_TRANSMISSION) > 0))
-            f = f + bxdf_f<FULL>(l, wo, wi);
+            f = f + bxdf_f<FEAT>(l, wo, wi);
     }
     return f;
 }
-template <bool FULL>
+template <int FEAT>
 RTD double bsdf_pdf(const Bsdf& b, D3 wow, D3 wiw, uint32_t flags) {  // bsdf.rs:166-189 (Q11)
-    int nc = num_components(b, RT_BSDF_ALL);
+    int nc = num_components<FEAT>(b, RT_BSDF_ALL);
     if (nc == 0) return 0.0;
     D3 wo = w2l(b, wow), wi = w2l(b, wiw);
     if (wo.z == 0.0) return 0.0;
     double pdf = 0.0;
     int matching = 0;
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < ((FEAT & kFeatTwo) ? 2 : 1); i++) {
         if (i >= nc) break;
         if (matches_flags(b.lobes[i].type, flags)) {
             matching++;
-            pdf += bxdf_pdf<FULL>(b.lobes[i], wo, wi);
+            pdf += bxdf_pdf<FEAT>(b.lobes[i], wo, wi);
         }
     }
     return matching > 0 ? pdf : 0.0;
 }
-template <bool FULL>
+template <int FEAT>
 RTD void bsdf_sample_f(const Bsdf& b, D3 wow, double u0, double u1, uint32_t type, uint64_t& rng, D3& color, D3& wiw,
                        double& pdf, uint32_t& sampled) {  // bsdf.rs:102-164
-    int matching = num_components(b, type);
+    int matching = num_components<FEAT>(b, type);
     color = black();
     wiw = black();
     pdf = 0.0;
@@ -426,7 +436,7 @@ RTD void bsdf_sample_f(const Bsdf& b, D3 wow, double u0, double u1, uint32_t typ
     if (comp_ > matching - 1) comp_ = matching - 1;
     int count = comp_, used = 0;
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < ((FEAT & kFeatTwo) ? 2 : 1); i++) {
         if (i >= b.n) break;
         if (matches_flags(b.lobes[i].type, type)) {
             if (count == 0) {
@@ -436,19 +446,19 @@ RTD void bsdf_sample_f(const Bsdf& b, D3 wow, double u0, double u1, uint32_t typ
             count--;
         }
     }
-    const Lobe l = pick_lobe(b, used);
+    const Lobe l = pick_lobe<FEAT>(b, used);
     D3 wo = normalize(w2l(b, wow));
     if (wo.z == 0.0) return;
     D3 f, wi;
     double p;
-    bxdf_sample_f<FULL>(l, wo, u0, u1, rng, f, wi, p);
+    bxdf_sample_f<FEAT>(l, wo, u0, u1, rng, f, wi, p);
     if (p == 0.0) return;
     D3 wiw_ = l2w(b, wi);
     if ((l.type & RT_BSDF_SPECULAR) == 0 && matching > 1) {
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             if (i >= b.n) break;
-            if (i != used && matches_flags(b.lobes[i].type, type)) p += bxdf_pdf<FULL>(b.lobes[i], wo, wi);
+            if (i != used && matches_flags(b.lobes[i].type, type)) p += bxdf_pdf<FEAT>(b.lobes[i], wo, wi);
         }
     }
     if (matching > 1) p = p / (double)matching;
@@ -461,7 +471,7 @@ RTD void bsdf_sample_f(const Bsdf& b, D3 wow, double u0, double u1, uint32_t typ
             const Lobe& li = b.lobes[i];
             if (matches_flags(li.type, type) && ((refl && (li.type & RT_BSDF_REFLECTION) > 0) ||
                                                  (!refl && (li.type & RT_BSDF_TRANSMISSION) > 0)))
-                f = f + bxdf_f<FULL>(li, wo, wi);
+                f = f + bxdf_f<FEAT>(li, wo, wi);
         }
     }
     color = f;
@@ -513,7 +523,7 @@ RTD D3 mat_tex(const DevScene& sc, const DevMat& dm, int k, double u, double v) 
 }
 
 // material.rs:80-244 with mode = RADIANCE, allow_lobes = true
-template <bool FULL>
+template <int FEAT>
 RTD void compute_scattering(const DevScene& sc, const HitRec& h, Bsdf& b) {
     const DevMat& dm = sc.mats[h.mat];
     const rt_material& m = dm.m;
@@ -527,7 +537,7 @@ RTD void compute_scattering(const DevScene& sc, const HitRec& h, Bsdf& b) {
             b.lobes[0] = make_lambert(color);
             b.n = 1;
         }
-    } else if (m.kind == RT_MAT_PLASTIC) {
+    } else if ((FEAT & kFeatTwo) && m.kind == RT_MAT_PLASTIC) {
         D3 color = mat_tex(sc, dm, 0, h.u, h.v);
         bool inited = false;
         if (!is_black(color)) {
@@ -551,13 +561,13 @@ RTD void compute_scattering(const DevScene& sc, const HitRec& h, Bsdf& b) {
                 b.lobes[1] = l;
             b.n++;
         }
-    } else if (m.kind == RT_MAT_GLASS) {
+    } else if ((FEAT & kFeatSpec) && m.kind == RT_MAT_GLASS) {
         D3 r = mat_tex(sc, dm, 0, h.u, h.v);
         D3 t = mat_tex(sc, dm, 1, h.u, h.v);
         bsdf_init(b, h);
         if (!(is_black(r) && is_black(t))) {
             double urough = m.f[0], vrough = m.f[1];
-            if (!FULL || (urough == 0.0 && vrough == 0.0)) {  // is_specular && allow_lobes
+            if (!((FEAT & kFeatFull) != 0) || (urough == 0.0 && vrough == 0.0)) {  // is_specular && allow_lobes
                 Lobe l = lobe_zero();
                 l.kind = LOBE_FRESNEL_SPECULAR;
                 l.type = RT_BSDF_TRANSMISSION | RT_BSDF_REFLECTION | RT_BSDF_SPECULAR;
@@ -595,7 +605,7 @@ RTD void compute_scattering(const DevScene& sc, const HitRec& h, Bsdf& b) {
                 }
             }
         }
-    } else if (m.kind == RT_MAT_METAL) {
+    } else if ((FEAT & kFeatMicro) && m.kind == RT_MAT_METAL) {
         bsdf_init(b, h);
         D3 ur = mat_tex(sc, dm, 3, h.u, h.v);
         D3 vr = mat_tex(sc, dm, 4, h.u, h.v);
@@ -607,7 +617,7 @@ RTD void compute_scattering(const DevScene& sc, const HitRec& h, Bsdf& b) {
         l.k = mat_tex(sc, dm, 1, h.u, h.v);
         b.lobes[0] = l;
         b.n = 1;
-    } else if (m.kind == RT_MAT_MIRROR) {
+    } else if ((FEAT & kFeatSpec) && m.kind == RT_MAT_MIRROR) {
         bsdf_init(b, h);
         D3 color = mat_tex(sc, dm, 0, h.u, h.v);
         if (!is_black(color)) {
