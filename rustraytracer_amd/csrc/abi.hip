@@ -440,10 +440,13 @@ int rt_scene_commit_ex(rt_scene* s, uint32_t flags) {
         d.env.light = (int32_t)i;
         need |= kFeatFull;
     }
-    s->shade_variant = 3;
-    for (int v = 3; v >= 0; v--)
+    s->shade_variant = kNumFeatVariants - 1;
+    for (int v = kNumFeatVariants - 1; v >= 0; v--)
         if ((need & ~kFeatVariants[v]) == 0) s->shade_variant = v;
-    if (const char* e = getenv("RT_SHADE_VARIANT")) s->shade_variant = std::max(s->shade_variant, std::min(3, atoi(e)));
+    if (const char* e = getenv("RT_SHADE_VARIANT")) {  // experiment: force a larger instance
+        const int v = std::min(kNumFeatVariants - 1, std::max(0, atoi(e)));
+        if ((need & ~kFeatVariants[v]) == 0) s->shade_variant = v;
+    }
     uint64_t n_tri = 0;
     uint32_t depth = 0;
     bool any_normals = false;
@@ -594,7 +597,9 @@ static ShadeKernel shade_kernel(int v) {
         case 0: return k_shade<kFeatVariants[0]>;
         case 1: return k_shade<kFeatVariants[1]>;
         case 2: return k_shade<kFeatVariants[2]>;
-        default: return k_shade<kFeatVariants[3]>;
+        case 3: return k_shade<kFeatVariants[3]>;
+        case 4: return k_shade<kFeatVariants[4]>;
+        default: return k_shade<kFeatVariants[5]>;
     }
 }
 static TailKernel tail_kernel(int v) {
@@ -602,7 +607,9 @@ static TailKernel tail_kernel(int v) {
         case 0: return k_tail<kFeatVariants[0]>;
         case 1: return k_tail<kFeatVariants[1]>;
         case 2: return k_tail<kFeatVariants[2]>;
-        default: return k_tail<kFeatVariants[3]>;
+        case 3: return k_tail<kFeatVariants[3]>;
+        case 4: return k_tail<kFeatVariants[4]>;
+        default: return k_tail<kFeatVariants[5]>;
     }
 }
 

@@ -258,8 +258,13 @@ constexpr int kFeatMicro = 1;  // microfacet lobes: Plastic, Metal (and rough Gl
 constexpr int kFeatSpec = 2;   // perfectly specular lobes: smooth Glass, Mirror
 constexpr int kFeatTwo = 4;    // two-lobe materials: Plastic (and rough Glass)
 constexpr int kFeatFull = 8;   // row f4: MicrofacetTransmission (rough Glass), the infinite light
-constexpr int kFeatVariants[4] = {0, kFeatMicro | kFeatSpec, kFeatMicro | kFeatSpec | kFeatTwo,
-                                  kFeatMicro | kFeatSpec | kFeatTwo | kFeatFull};
+constexpr int kNumFeatVariants = 6;
+constexpr int kFeatVariants[kNumFeatVariants] = {0,
+                                                 kFeatMicro,
+                                                 kFeatSpec,
+                                                 kFeatMicro | kFeatSpec,
+                                                 kFeatMicro | kFeatSpec | kFeatTwo,
+                                                 kFeatMicro | kFeatSpec | kFeatTwo | kFeatFull};
 template <int FEAT>
 RTD D3 bxdf_f(const Lobe& l, D3 wo, D3 wi) {
     if (l.kind == LOBE_LAMBERT) return l.color * kInvPi;
