@@ -78,7 +78,7 @@ struct rt_context {
     size_t pix_capacity = 0;
     std::vector<hipEvent_t> events;
     TraceTune tune{32, 4, 0, 128};
-    uint32_t tail_paths = 131072;  // switch to the fused tail kernel at or below this many live paths
+    uint32_t tail_paths = 393216;  // switch to the fused tail kernel at or below this many live paths
 };
 
 struct rt_scene {

@@ -646,12 +646,15 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 2
 #endif
+#ifndef RT_SHADE4_MAXFEAT
+#define RT_SHADE4_MAXFEAT (-1)  // (experiment) instances up to this mask compiled for 4 waves/SIMD
+#endif
 #ifndef RT_SHADE3_MAXFEAT
 #define RT_SHADE3_MAXFEAT 3  // instances up to this feature mask are compiled for 3 waves/SIMD (measured: the
                              // two-lobe and row-f4 instances spill too much to gain from it)
 #endif
 template <int FEAT>
-__global__ __launch_bounds__(256, FEAT <= RT_SHADE3_MAXFEAT ? 3 : RT_SHADE_WAVES) void k_shade(DevScene sc, PathState in, PathState out, Ctl* ctl, uint32_t it_abs,
+__global__ __launch_bounds__(256, FEAT <= RT_SHADE4_MAXFEAT ? 4 : (FEAT <= RT_SHADE3_MAXFEAT ? 3 : RT_SHADE_WAVES)) void k_shade(DevScene sc, PathState in, PathState out, Ctl* ctl, uint32_t it_abs,
                                                uint32_t max_depth, uint32_t* queue_out, double* lfx, double* lfy,
                                                double* lfz, DevStats* stats) {
     const uint32_t it = it_abs % kRing, itn = (it_abs + 1) % kRing;
