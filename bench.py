@@ -222,6 +222,9 @@ def main():
                          "tris_per_ray": stc.tris_tested / max(stc.rays, 1),
                          "trace_share_of_device_time": trace_ms / max(kernel_ms, 1e-9)},
             "device_ms_per_step": kernel_ms / args.steps,
+            # also paths/s and the mean path length (rays per camera sample), whole job
+            "mpaths_per_s": W * H * spp * args.steps / dt_max / 1e6,
+            "mean_rays_per_path": rays_all / args.steps / (W * H * spp),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, W, H)
