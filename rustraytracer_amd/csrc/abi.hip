@@ -514,6 +514,9 @@ int rt_scene_commit_ex(rt_scene* s, uint32_t flags) {
     s->info.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     s->info.build_flags = flags;
     d.n_prims = (uint32_t)np;
+    d.simple_others = getenv("RT_NO_SIMPLE_OTHERS") ? 0u : 1u;
+    for (const rt_primitive& p : s->prims)
+        if (p.kind == RT_PRIM_SPHERE || (p.kind != RT_PRIM_TRIANGLE && p.xform_index >= 0)) d.simple_others = 0u;
     d.n_lights = (uint32_t)s->lights.size();
     d.mesh_has_uv = has_uv;
     s->info.n_prims = np;
@@ -688,11 +691,11 @@ static int run_lane(RenderJob& job, int lane_id) {
         }
         const uint32_t seq = seq0 + (uint32_t)it;
         if (job.count_trav)
-            hipLaunchKernelGGL(k_trace<true>, dim3(tblocks), dim3(256), 0, stream, job.s->dev, ln.st[it & 1],
+            hipLaunchKernelGGL((k_trace<true, false>), dim3(tblocks), dim3(256), 0, stream, job.s->dev, ln.st[it & 1],
                                ln.queue[it & 1], ln.ctl, (uint32_t)it, c->stats, c->tune, no_mirror ? nullptr : ln.mirror_d, seq, c->batch,
                                job.batch_total);
         else
-            hipLaunchKernelGGL(k_trace<false>, dim3(tblocks), dim3(256), 0, stream, job.s->dev, ln.st[it & 1],
+            hipLaunchKernelGGL((job.s->dev.simple_others ? k_trace<false, true> : k_trace<false, false>), dim3(tblocks), dim3(256), 0, stream, job.s->dev, ln.st[it & 1],
                                ln.queue[it & 1], ln.ctl, (uint32_t)it, c->stats, c->tune, no_mirror ? nullptr : ln.mirror_d, seq, c->batch,
                                job.batch_total);
         if (!no_ev) {
@@ -803,8 +806,8 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
         job.count_trav = (cfg->flags & RT_RENDER_COUNT_TRAVERSAL) != 0;
         // persistent grid = what is resident at once (more blocks would only queue behind them)
         int occ_t = 0, occ_c = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_t, k_trace<false>, 256, 0));
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, k_trace<true>, 256, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_t, s->dev.simple_others ? k_trace<false, true> : k_trace<false, false>, 256, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, k_trace<true, false>, 256, 0));
         int per_cu = std::max(1, job.count_trav ? occ_c : occ_t);
         if (const char* e = getenv("RT_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));
         job.trace_blocks = c->num_cus * per_cu;

@@ -194,7 +194,7 @@ struct TraceTune {
     int reserve;       // queue entries a wave reserves per atomic (refills are served from the reservation)
 };
 
-template <bool COUNT>
+template <bool COUNT, bool SIMPLE>
 __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, PathState st, const uint32_t* __restrict__ queue,
                                                Ctl* ctl, uint32_t it_abs, DevStats* stats, TraceTune tune,
                                                MirrorEntry* mirror, uint32_t seq, const BatchCtl* batch,
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
                 diag_rounds[2]++;
                 diag_rounds[3] += (uint32_t)cl;
             }
-            if (at_leaf) leaf_step<COUNT>(tv, sc, ts, &tc);
+            if (at_leaf) leaf_step<COUNT, SIMPLE>(tv, sc, ts, &tc);
         }
         if (has_ray && tv.done) {
             if (COUNT) {  // diagnostic: longest traversal, and how many rays needed more than 64 / 256 steps

@@ -82,6 +82,7 @@ struct DevScene {
     const rt_texture* texs;
     const rt_light* lights;
     uint32_t n_prims, n_lights, n_nodes, mesh_has_uv;  // mesh_has_uv: any mesh carries uvs
+    uint32_t simple_others, pad_so;                   // no sphere and no transformed rect in the scene
     DevEnv env;
 };
 
