@@ -476,3 +476,25 @@ def test_rough_glass_in_the_cornell_box(gpu_ctx):
     assert np.array_equal(rg, ro) and np.array_equal(ng, no) and sg.rays == so.rays
     assert rmse(rg, ng, ro, no) < RMSE_TOL
     gs.close()
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "cornell_statue_plastic", "dragon_glass", "two_dragons",
+                                  "material_hdr_rough_glass", "sphere_roughness"])
+def test_gpu_matches_committed_oracle_films(gpu_ctx, name):
+    """The HIP path against the committed fixtures (tests/golden/oracle_films.npz): bit for bit, ray counters too."""
+    import importlib.util
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_oracle_films", os.path.join(here, "make_oracle_films.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    gold = np.load(os.path.join(here, "oracle_films.npz"))
+    make, w, h, spp, seed = mod.CASES[name]
+    sc = make()
+    gs = gpu_ctx.upload(sc)
+    rgb, n, st = gpu_ctx.render(gs, sc.camera, rr.make_cfg(w, h, spp, seed=seed))
+    counts = np.array([st.rays_extension, st.rays_shadow, st.rays_probe, st.vertices_shaded], dtype=np.uint64)
+    assert np.array_equal(counts, gold[name + "_counts"])
+    assert np.array_equal(rgb, gold[name + "_rgb"], equal_nan=True)
+    assert rmse(np.nan_to_num(rgb), n, np.nan_to_num(gold[name + "_rgb"]), n) < RMSE_TOL
+    gs.close()

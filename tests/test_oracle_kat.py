@@ -519,3 +519,20 @@ def test_oracle_renders_environment_lit_scene():
     assert np.array_equal(a, b) and sa.rays == sb.rays
     assert np.isfinite(a).all() and a.mean() > 0.01       # the sky lights everything
     assert sa.rays_shadow > 0 and sa.rays_probe > 0
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "cornell_statue_plastic", "dragon_glass", "two_dragons",
+                                  "material_hdr_rough_glass", "sphere_roughness"])
+def test_oracle_regression_films(name):
+    """The oracle against its own committed films (tests/golden/oracle_films.npz, make_oracle_films.py): not a
+    pin to the reference (impossible here) but a guard against accidental drift of the restatement."""
+    import importlib.util
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_oracle_films", os.path.join(here, "make_oracle_films.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    gold = np.load(os.path.join(here, "oracle_films.npz"))
+    rgb, counts = mod.render(name)
+    assert np.array_equal(counts, gold[name + "_counts"])
+    assert np.array_equal(rgb, gold[name + "_rgb"], equal_nan=True)
