@@ -140,7 +140,9 @@ def main():
     gather = rd.FilmGather(W, H, coll_dev) if world > 1 else None
 
     def step():
-        st = ctx.render_device(gs, scene.camera, cfg, d_rgb.data_ptr(), d_n.data_ptr())
+        # on torch's current stream, so that the film zeroing of the next step is ordered after this step's gather
+        st = ctx.render_device(gs, scene.camera, cfg, d_rgb.data_ptr(), d_n.data_ptr(),
+                               stream=torch.cuda.current_stream().cuda_stream)
         if gather is not None:
             # the path's only exchange step: each rank's own tiles go straight to rank 0 (RCCL over xGMI)
             if coll_dev == "cuda":
