@@ -498,3 +498,30 @@ def test_gpu_matches_committed_oracle_films(gpu_ctx, name):
     assert np.array_equal(rgb, gold[name + "_rgb"], equal_nan=True)
     assert rmse(np.nan_to_num(rgb), n, np.nan_to_num(gold[name + "_rgb"]), n) < RMSE_TOL
     gs.close()
+
+
+def test_intersect_batch_extreme_rays(gpu_ctx):
+    """The conservative f32 interior-node test (geom.h: node_consts) under stress: far origins, directions from
+    1e-45 to 1e30 in magnitude (1/d overflows or underflows f32), axis-parallel and in-plane rays, origins on box
+    planes.  The culling may get looser, the closest hit must not change."""
+    sc = rr.cornell_box_statue(mesh_faces=30000, variant=0)
+    osc = O.OracleScene(sc)
+    rng = np.random.default_rng(77)
+    n = 60000
+    for gs in (gpu_ctx.upload(sc), gpu_ctx.upload(sc, device_build=True)):
+        o = rng.uniform(-50.0, 600.0, size=(n, 3))
+        d = rng.normal(size=(n, 3))
+        o[:5000] *= 1e4                                   # far away: o * inv32 loses all absolute precision
+        d[5000:15000] *= 10.0 ** rng.uniform(-45, 30, size=(10000, 1))
+        d[15000:20000, rng.integers(0, 3)] = 0.0
+        d[20000:22000, :2] = 0.0
+        d[22000:24000] *= np.array([1.0, 1e-12, 1e-25])   # nearly axis-parallel
+        o[24000:26000, 0] = 555.0                         # on the planes of the walls' boxes
+        o[26000:28000, 1] = 0.0
+        o[28000:30000] = np.array([278.0, 278.0, -800.0])  # the preset's camera position
+        for tmin in (F.RT_SMALL, 0.0):
+            tg, pg = gpu_ctx.intersect_batch(gs, o, d, tmin)
+            to, po = osc.intersect_batch(o, d, tmin)
+            assert np.array_equal(pg, po), f"{(pg != po).sum()} prim mismatches"
+            assert np.array_equal(tg, to, equal_nan=True)
+        gs.close()
