@@ -478,7 +478,7 @@ RTD void stack_get(const TravStack& ts, int sp, int32_t& node, float& t) {
 // node-only rounds and then primitive-only rounds (while-while traversal) and refill finished lanes
 // in between (k_trace), or simply loop to completion (closest_hit):
 //   cur >= 0            at an internal node          -> node_step()
-//   cur <  0 (not done) at a leaf, leaf_i-th primitive next -> leaf_step()
+//   cur <  0 (not done) at a leaf, its first remaining primitive next -> leaf_step()
 struct Trav {
     D3 op, ip;  // origin and 1/dir, PERMUTED to the triangle test's (kx, ky, kz) axis order
     // f32 constants of the conservative interior-node test (node_step): t = fma(plane, inv32, c),
@@ -489,7 +489,6 @@ struct Trav {
     int32_t best_prim, cur;
     uint32_t best_slot;  // leaf slot of best_prim (| kLeafOther)
     int sp;
-    uint32_t leaf_i;
     bool done;
 };
 
@@ -535,7 +534,6 @@ RTD void trav_init(Trav& tv, const DevScene& sc, D3 o, D3 dir, double tmin, doub
     tv.best_slot = 0;
     tv.cur = 0;
     tv.sp = 0;
-    tv.leaf_i = 0;
     // A ray with a NaN component (Q17: NaNs are never filtered) passes every slab test and "hits" whatever
     // triangle is visited first, i.e. the reference's answer depends on its random tree.  The ABI pins it:
     // such a ray misses.
@@ -562,8 +560,7 @@ RTD void trav_pop(Trav& tv, TravStack& ts) {
         stack_get(ts, tv.sp, node, et);
         if ((double)et <= lim2) {
             tv.cur = node;
-            tv.leaf_i = 0;
-            return;
+                    return;
         }
     }
     tv.done = true;
@@ -608,7 +605,6 @@ RTD void node_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
     RT_NODE_CHILD(z, e2, h2, ch.z)
     RT_NODE_CHILD(w, e3, h3, ch.w)
 #undef RT_NODE_CHILD
-    tv.leaf_i = 0;
     // sort the hit children by entry distance (misses sink to the end as +inf): 5-comparator network
     const float kMiss = __builtin_huge_valf();
     float d0 = h0 ? e0 : kMiss, d1 = h1 ? e1 : kMiss;
@@ -647,7 +643,7 @@ RTD void leaf_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
     const double tmin = tv.tmin, tmax = tv.tmax;
     const uint32_t code = (uint32_t)(-1 - tv.cur);
     const uint32_t first = (code & ~kLeafCodeOther) >> 3, count = (code & 7u) + 1u;
-    const uint32_t slot = first + tv.leaf_i;
+    const uint32_t slot = first;
     const uint32_t e = sc.leaf_prim[slot];
     const double* tvp = sc.leaf_tri + (size_t)slot * 9;
     double t = 0.0;
@@ -680,7 +676,9 @@ RTD void leaf_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
         tn = hmax(tn, hmin(lo, hi));
         tf = hmin(tf, hmax(lo, hi));
         double b0, b1, b2;
-        hit = !(tf <= tn) && tri_core_t(p0t, p1t, p2t, tv.trr, tmax, t, b0, b1, b2);
+        TriRay trz = tv.trr;
+        trz.s_z = ip.z;  // 1 / dir[kz]: the same value as tri_ray()'s s_z, so that need not stay in a register
+        hit = !(tf <= tn) && tri_core_t(p0t, p1t, p2t, trz, tmax, t, b0, b1, b2);
         pi = (int32_t)e;
         if (hit && sc.mesh_has_uv) {  // rare path: uv-degenerate rejection (hittable.rs:373-378)
             const rt_primitive& pr = sc.prims[pi];
@@ -743,8 +741,11 @@ RTD void leaf_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
         tv.best_prim = pi;
         tv.best_slot = slot | (e & kLeafOther);
     }
-    tv.leaf_i++;
-    if (tv.leaf_i >= count) trav_pop(tv, ts);
+    // the rest of the leaf is the leaf (first + 1, count - 1): no separate cursor to keep in a register
+    if (count > 1u)
+        tv.cur = -1 - (int32_t)((((first + 1u) << 3) | (count - 2u)) | (code & kLeafCodeOther));
+    else
+        trav_pop(tv, ts);
 }
 
 // Closest hit of one ray, run to completion.  Returns prim index or -1; t_out = hit parameter.
