@@ -717,7 +717,15 @@ static int run_lane(RenderJob& job, int lane_id) {
     return RT_OK;
 }
 
-constexpr size_t kBatchMax = (size_t)1 << 26;  // camera samples per batch (film staging: 24 B each)
+static size_t batch_max() {  // camera samples per batch (film staging: 24 B each)
+    static const size_t v = [] {
+        size_t lg = 28;  // 6.4 GB of staging: fewer pool drains per frame on the large configurations
+        if (const char* e = getenv("RT_BATCH_LOG2")) lg = (size_t)std::min(31, std::max(16, atoi(e)));
+        return (size_t)1 << lg;
+    }();
+    return v;
+}
+#define kBatchMax (batch_max())
 
 static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const rt_render_cfg* cfg, double* d_rgb,
                        uint32_t* d_n, hipStream_t stream, rt_stats* stats) {
