@@ -780,7 +780,9 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
         }
         const size_t batch_cap = (size_t)PB * ns;
         // pool per lane
-        uint32_t P = cfg->paths_in_flight ? cfg->paths_in_flight : (1u << 24);
+        // default pool: 64 Mi paths (33 GB of path state when a batch is that large; smaller batches size it down).
+        // Fewer, fuller launches: C3 -3.5 %, C4 -4.6 % against 16 Mi.
+        uint32_t P = cfg->paths_in_flight ? cfg->paths_in_flight : (1u << 26);
         P = std::max<uint32_t>(64u, std::min<uint32_t>(P, 1u << 26));
         P = (P + 63u) & ~63u;
         const int n_lanes = (batch_cap > (size_t)P) ? c->n_lanes : 1;
