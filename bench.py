@@ -33,6 +33,8 @@ WORKLOADS = {
            "C2 cornell_box_statue (matte) + procedural P-400k mesh, 512x512 @ 64 spp, max_depth 25"),
     "c3": ("plastic_dragon", dict(mesh_faces=871414, variant=1), 1024, 1024, 256,
            "C3 dragon (procedural P-871k) microfacet metal, 1024x1024 @ 256 spp, max_depth 25"),
+    "c3p": ("plastic_dragon", dict(mesh_faces=871414, variant=0), 1024, 1024, 256,
+            "plastic_dragon() as committed in scenes.rs:310-375 (plastic, two lobes), procedural P-871k, 1024x1024 @ 256 spp"),
     "c4": ("two_dragons", dict(mesh_faces=871414, variant=0), 1920, 1080, 1024,
            "C4 two_dragons (glass + metal, 2 x procedural P-871k), 1920x1080 @ 1024 spp, max_depth 25"),
     "c5": ("plastic_dragon", dict(mesh_faces=871414, variant=2), 2048, 2048, 4096,
