@@ -41,6 +41,8 @@ WORKLOADS = {
            "C5 dragon (procedural P-871k) smooth glass, 2048x2048 @ 4096 spp, max_depth 25"),
     "hdr": ("material_hdr", dict(variant=3, mesh_faces=150000), 512, 512, 64,
             "row f4: material_hdr(3) rough glass under the procedural environment map, 3 x P-150k, 512x512 @ 64 spp"),
+    "hdr1": ("material_hdr", dict(variant=1, mesh_faces=150000), 512, 512, 64,
+             "row f4: material_hdr(1) rose-gold metal under the procedural environment map, 3 x P-150k, 512x512 @ 64 spp"),
     "c1": ("cornell_box", dict(), 256, 256, 16, "C1 cornell_box 256x256 @ 16 spp"),
     "tiny": ("cornell_box_statue", dict(mesh_faces=20000, variant=0), 128, 128, 8, "tiny smoke workload"),
 }

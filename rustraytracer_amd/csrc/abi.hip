@@ -423,7 +423,7 @@ int rt_scene_commit_ex(rt_scene* s, uint32_t flags) {
         if (m.kind == RT_MAT_PLASTIC) need |= kFeatMicro | kFeatTwo;
         if (m.kind == RT_MAT_METAL) need |= kFeatMicro;
         if (m.kind == RT_MAT_MIRROR) need |= kFeatSpec;
-        if (m.kind == RT_MAT_GLASS) need |= (m.f[0] != 0.0 || m.f[1] != 0.0) ? kFeatFull : kFeatSpec;
+        if (m.kind == RT_MAT_GLASS) need |= (m.f[0] != 0.0 || m.f[1] != 0.0) ? (kFeatTrans | kFeatMicro | kFeatTwo) : kFeatSpec;
     }
     for (size_t i = 0; i < s->lights.size(); i++) {
         if (s->lights[i].kind != RT_LIGHT_INFINITE) continue;
@@ -438,7 +438,7 @@ int rt_scene_commit_ex(rt_scene* s, uint32_t flags) {
         d.env.nu = ed.nu;
         d.env.nv = ed.nv;
         d.env.light = (int32_t)i;
-        need |= kFeatFull;
+        need |= kFeatEnv;
     }
     s->shade_variant = kNumFeatVariants - 1;
     for (int v = kNumFeatVariants - 1; v >= 0; v--)
@@ -602,7 +602,10 @@ static ShadeKernel shade_kernel(int v) {
         case 2: return k_shade<kFeatVariants[2]>;
         case 3: return k_shade<kFeatVariants[3]>;
         case 4: return k_shade<kFeatVariants[4]>;
-        default: return k_shade<kFeatVariants[5]>;
+        case 5: return k_shade<kFeatVariants[5]>;
+        case 6: return k_shade<kFeatVariants[6]>;
+        case 7: return k_shade<kFeatVariants[7]>;
+        default: return k_shade<kFeatVariants[8]>;
     }
 }
 static TailKernel tail_kernel(int v) {
@@ -612,7 +615,10 @@ static TailKernel tail_kernel(int v) {
         case 2: return k_tail<kFeatVariants[2]>;
         case 3: return k_tail<kFeatVariants[3]>;
         case 4: return k_tail<kFeatVariants[4]>;
-        default: return k_tail<kFeatVariants[5]>;
+        case 5: return k_tail<kFeatVariants[5]>;
+        case 6: return k_tail<kFeatVariants[6]>;
+        case 7: return k_tail<kFeatVariants[7]>;
+        default: return k_tail<kFeatVariants[8]>;
     }
 }
 

@@ -451,7 +451,7 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool va
         if (fl & (kHasShadow | kHasProbe)) {
             const uint32_t light_idx = fl >> kLightShift;
             const rt_light& lt = sc.lights[light_idx];
-            const bool infinite = ((FEAT & kFeatFull) != 0) && lt.kind == RT_LIGHT_INFINITE;
+            const bool infinite = ((FEAT & kFeatEnv) != 0) && lt.kind == RT_LIGHT_INFINITE;
             D3 ld = black();
             if (fl & kHasShadow) {
                 // Visibility::unoccluded(infinite): an area light must be the closest hit, the environment needs a miss
@@ -497,7 +497,7 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool va
             if (is_some) {
                 const int32_t li = a.rec.light;
                 if (li >= 0) a.L = a.L + cmul(light_l(sc.lights[li], a.rec.n, -a.d), a.beta);
-            } else if (((FEAT & kFeatFull) != 0) && sc.env.light >= 0) {
+            } else if (((FEAT & kFeatEnv) != 0) && sc.env.light >= 0) {
                 // escaped: every light adds le(ray), black for all but the infinite one (light.rs:499-512)
                 a.L = a.L + cmul(infinite_le(sc, sc.lights[sc.env.light], a.d), a.beta);
             }
@@ -533,7 +533,7 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
         const double ul0 = rng_next(rng), ul1 = rng_next(rng);
         const double us0 = rng_next(rng), us1 = rng_next(rng);
         const rt_light& lt = sc.lights[light_num];
-        const bool infinite = ((FEAT & kFeatFull) != 0) && lt.kind == RT_LIGHT_INFINITE;
+        const bool infinite = ((FEAT & kFeatEnv) != 0) && lt.kind == RT_LIGHT_INFINITE;
         const rt_primitive& lp = sc.prims[infinite ? 0u : lt.prim_index];
         const uint32_t nsf = RT_BSDF_ALL - RT_BSDF_SPECULAR;
         const D3 ltcolor = d3(lt.color[0], lt.color[1], lt.color[2]);
@@ -654,7 +654,7 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
                              // two-lobe and row-f4 instances spill too much to gain from it)
 #endif
 template <int FEAT>
-__global__ __launch_bounds__(256, FEAT <= RT_SHADE4_MAXFEAT ? 4 : (FEAT <= RT_SHADE3_MAXFEAT ? 3 : RT_SHADE_WAVES)) void k_shade(DevScene sc, PathState in, PathState out, Ctl* ctl, uint32_t it_abs,
+__global__ __launch_bounds__(256, FEAT <= RT_SHADE4_MAXFEAT ? 4 : (feat_three_waves(FEAT) && RT_SHADE3_MAXFEAT >= 3 ? 3 : RT_SHADE_WAVES)) void k_shade(DevScene sc, PathState in, PathState out, Ctl* ctl, uint32_t it_abs,
                                                uint32_t max_depth, uint32_t* queue_out, double* lfx, double* lfy,
                                                double* lfz, DevStats* stats) {
     const uint32_t it = it_abs % kRing, itn = (it_abs + 1) % kRing;

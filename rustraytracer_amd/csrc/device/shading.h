@@ -257,14 +257,20 @@ RTD bool matches_flags(uint32_t flag, uint32_t other) { return (flag & other) ==
 constexpr int kFeatMicro = 1;  // microfacet lobes: Plastic, Metal (and rough Glass)
 constexpr int kFeatSpec = 2;   // perfectly specular lobes: smooth Glass, Mirror
 constexpr int kFeatTwo = 4;    // two-lobe materials: Plastic (and rough Glass)
-constexpr int kFeatFull = 8;   // row f4: MicrofacetTransmission (rough Glass), the infinite light
-constexpr int kNumFeatVariants = 6;
+constexpr int kFeatTrans = 8;   // row f4: MicrofacetTransmission (rough Glass; comes with kFeatMicro | kFeatTwo)
+constexpr int kFeatEnv = 16;    // row f4: the infinite light and its HDR map
+constexpr int kNumFeatVariants = 9;
 constexpr int kFeatVariants[kNumFeatVariants] = {0,
                                                  kFeatMicro,
                                                  kFeatSpec,
                                                  kFeatMicro | kFeatSpec,
                                                  kFeatMicro | kFeatSpec | kFeatTwo,
-                                                 kFeatMicro | kFeatSpec | kFeatTwo | kFeatFull};
+                                                 kFeatMicro | kFeatSpec | kFeatEnv,
+                                                 kFeatMicro | kFeatSpec | kFeatTwo | kFeatEnv,
+                                                 kFeatMicro | kFeatSpec | kFeatTwo | kFeatTrans,
+                                                 kFeatMicro | kFeatSpec | kFeatTwo | kFeatTrans | kFeatEnv};
+// instances without two-lobe materials are compiled for 3 waves/SIMD (kernels.hip)
+constexpr bool feat_three_waves(int feat) { return (feat & (kFeatTwo | kFeatTrans)) == 0; }
 template <int FEAT>
 RTD D3 bxdf_f(const Lobe& l, D3 wo, D3 wi) {
     if (l.kind == LOBE_LAMBERT) return l.color * kInvPi;
@@ -278,7 +284,7 @@ RTD D3 bxdf_f(const Lobe& l, D3 wo, D3 wi) {
         D3 comp1 = l.color * tr_d(l.alpha_x, l.alpha_y, wh) * tr_g(l.alpha_x, l.alpha_y, wo, wi);
         return cmul(comp1, f * (1.0 / (4.0 * cos_i * cos_o)));
     }
-    if (((FEAT & kFeatFull) != 0) && l.kind == LOBE_MICRO_TRANS) {  // bxdf.rs:393-441 (mode == RADIANCE); eta_a = p0, eta_b = p1
+    if (((FEAT & kFeatTrans) != 0) && l.kind == LOBE_MICRO_TRANS) {  // bxdf.rs:393-441 (mode == RADIANCE); eta_a = p0, eta_b = p1
         if (same_hemisphere(wo, wi)) return black();
         const double cos_theta_o = wo.z, cos_theta_i = wi.z;
         if (cos_theta_i == 0.0 || cos_theta_o == 0.0) return black();
@@ -305,7 +311,7 @@ RTD double bxdf_pdf(const Lobe& l, D3 wo, D3 wi) {
         D3 wh = normalize(wo + wi);
         return tr_pdf(l.alpha_x, l.alpha_y, wo, wh) / (4.0 * dot(wo, wh));
     }
-    if (((FEAT & kFeatFull) != 0) && l.kind == LOBE_MICRO_TRANS) {  // bxdf.rs:742-763
+    if (((FEAT & kFeatTrans) != 0) && l.kind == LOBE_MICRO_TRANS) {  // bxdf.rs:742-763
         if (same_hemisphere(wo, wi)) return 0.0;
         const double eta = wo.z > 0.0 ? l.p1 / l.p0 : l.p0 / l.p1;
         const D3 wh = normalize(wo + wi * eta);
@@ -356,7 +362,7 @@ RTD void bxdf_sample_f(const Lobe& l, D3 wo, double u0, double u1, uint64_t& rng
             wi = dirv;
             pdf = 1.0 - fr;
         }
-    } else if (((FEAT & kFeatFull) != 0) && l.kind == LOBE_MICRO_TRANS) {  // bxdf.rs:608-638
+    } else if (((FEAT & kFeatTrans) != 0) && l.kind == LOBE_MICRO_TRANS) {  // bxdf.rs:608-638
         if (wo.z == 0.0) return;
         const D3 wh = tr_sample_wh(l.alpha_x, l.alpha_y, wo, u0, u1);
         if (dot(wo, wh) < 0.0) return;
@@ -572,7 +578,7 @@ RTD void compute_scattering(const DevScene& sc, const HitRec& h, Bsdf& b) {
         bsdf_init(b, h);
         if (!(is_black(r) && is_black(t))) {
             double urough = m.f[0], vrough = m.f[1];
-            if (!((FEAT & kFeatFull) != 0) || (urough == 0.0 && vrough == 0.0)) {  // is_specular && allow_lobes
+            if (!((FEAT & kFeatTrans) != 0) || (urough == 0.0 && vrough == 0.0)) {  // is_specular && allow_lobes
                 Lobe l = lobe_zero();
                 l.kind = LOBE_FRESNEL_SPECULAR;
                 l.type = RT_BSDF_TRANSMISSION | RT_BSDF_REFLECTION | RT_BSDF_SPECULAR;

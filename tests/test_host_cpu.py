@@ -78,8 +78,8 @@ def test_library_exports_every_declared_symbol():
     blob = open(F.LIB_PATH, "rb").read()
     assert b"amdgcn-amd-amdhsa--gfx950" in blob
     # every kernel instance the launch tables of abi.hip can pick is in the library: the six shading / tail
-    # instances (feature masks 0, 1, 2, 3, 7, 15), the traversal kernel with and without counters / simple leaves
-    for feat in (0, 1, 2, 3, 7, 15):
+    # instances (feature masks of shading.h: kFeatVariants), the traversal kernel with and without counters / simple leaves
+    for feat in (0, 1, 2, 3, 7, 19, 23, 15, 31):
         assert b"_ZN3rtd7k_shadeILi%dEEE" % feat in blob and b"_ZN3rtd6k_tailILi%dEEE" % feat in blob
     for inst in (b"k_traceILb0ELb0E", b"k_traceILb0ELb1E", b"k_traceILb1ELb0E", b"k_intersect_batch", b"k_generate",
                  b"k_resolve", b"k_tonemap", b"kb_scatter", b"kb_emit"):
