@@ -77,7 +77,7 @@ struct rt_context {
     uint32_t* pix_list = nullptr;
     size_t pix_capacity = 0;
     std::vector<hipEvent_t> events;
-    TraceTune tune{32, 4, 0, 128};
+    TraceTune tune{24, 4, 0, 128};
     uint32_t tail_paths = 393216;  // switch to the fused tail kernel at or below this many live paths
 };
 

@@ -236,13 +236,18 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
     tv.done = true;
     tv.cur = 0;
     bool has_ray = false;
+    bool wb = false;  // this lane's finished ray still has to write its result (done in refill rounds)
     uint32_t ray_steps0 = 0;
     uint32_t diag_rounds[4] = {0, 0, 0, 0};  // wave-uniform diagnostics (instrumented build only)
     bool exhausted = false;  // wave-uniform: the queue and this wave's reservation have no more entries
     uint32_t slot_kind = 0;
     uint32_t res_next = 0, res_end = 0;  // wave-uniform: [res_next, res_end) is reserved for this wave
     uint32_t res_base = 0, q_lo = 0, q_hi = 0;  // start of the reservation; its queue entries, two per lane
-    // small queues: shrink the reservation so that the tail still spreads over the waves
+    // One atomic on the queue head hands a wave `reserve` entries.  128 is the measured optimum: 64 costs 30 % of the
+    // kernel's time (twice the atomic -> queue -> ray-data chains); larger reservations served through a sliding
+    // 128-entry window were 5-10 % slower (the extra code in the refill path, and neighbouring queue entries are
+    // neighbouring paths: small reservations let concurrent waves share their nodes in L2).
+    // Small queues: shrink the reservation so that the tail still spreads over the waves.
     const uint32_t n_waves = gridDim.x * 4u;
     uint32_t reserve = (uint32_t)tune.reserve;
     if (reserve > 128u) reserve = 128u;  // two cached entries per lane
@@ -250,6 +255,21 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
     for (;;) {
         const unsigned long long idle = __ballot(!has_ray);
         const int n_idle = __popcll(idle);
+        // Results are written in refill rounds only: a store in flight delays every later `s_waitcnt vmcnt`
+        // (loads and stores share the counter), and some lane finishes in almost every round.
+        if (n_idle >= tune.refill_lanes || exhausted) {
+            if (wb) {
+                const uint32_t slot = slot_kind & kSlotMask, kind = slot_kind >> 30;
+                if (kind == kRayExt) {
+                    st.hit_prim[slot] = tv.best_prim;
+                    st.hit_slot[slot] = tv.best_slot;
+                } else if (kind == kRayShadow)
+                    st.sh_prim[slot] = tv.best_prim;
+                else
+                    st.pr_prim[slot] = tv.best_prim;
+                wb = false;
+            }
+        }
         if (!exhausted && (n_idle >= tune.refill_lanes)) {
             if (res_next >= res_end) {
                 uint32_t base = 0;
@@ -327,15 +347,7 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
                 if (steps > 64u) atomicAdd(&stats->pad[4], 1ull);
                 if (steps > 256u) atomicAdd(&stats->pad[5], 1ull);
             }
-            const uint32_t slot = slot_kind & kSlotMask, kind = slot_kind >> 30;
-            if (kind == kRayExt) {
-                st.hit_prim[slot] = tv.best_prim;
-                st.hit_slot[slot] = tv.best_slot;
-            }
-            else if (kind == kRayShadow)
-                st.sh_prim[slot] = tv.best_prim;
-            else
-                st.pr_prim[slot] = tv.best_prim;
+            wb = true;
             has_ray = false;
         }
     }
