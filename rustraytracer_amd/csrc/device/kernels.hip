@@ -665,18 +665,70 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
 #define RT_SHADE3_MAXFEAT 3  // instances up to this feature mask are compiled for 3 waves/SIMD (measured: the
                              // two-lobe and row-f4 instances spill too much to gain from it)
 #endif
+#ifndef RT_SORT_CLASSES
+#define RT_SORT_CLASSES 5
+#endif
 template <int FEAT>
 __global__ __launch_bounds__(256, FEAT <= RT_SHADE4_MAXFEAT ? 4 : (feat_three_waves(FEAT) && RT_SHADE3_MAXFEAT >= 3 ? 3 : RT_SHADE_WAVES)) void k_shade(DevScene sc, PathState in, PathState out, Ctl* ctl, uint32_t it_abs,
                                                uint32_t max_depth, uint32_t* queue_out, double* lfx, double* lfy,
                                                double* lfz, DevStats* stats) {
     const uint32_t it = it_abs % kRing, itn = (it_abs + 1) % kRing;
     const uint32_t n_active = ctl->n_active[it];
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     // whole block past the end: nothing to do (block-uniform exit: the block barriers below stay well-formed)
     if (blockIdx.x * blockDim.x >= n_active) return;
     __shared__ uint32_t s_cnt[4][4];  // [wave][0 = output slots, 1..3 = ext / shadow / probe rays]
     __shared__ uint32_t s_base[2];    // block's base in the next path list / ray queue
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // Deal the block's 256 paths to its lanes by what their vertex needs (mesh hit / sphere-rect hit / escaped /
+    // fold only / nothing), so that the lanes of a wave run the same branches: the shading kernels are VALU-bound
+    // at 24-35 active lanes of 64 (PMC).  Paths are independent and the film staging is indexed by
+    // (pixel, sample), so the order inside a block changes no result.  Scenes with Lambertian materials only
+    // (FEAT == 0, e.g. C2) have nothing to separate and skip it; C3 +3.8 %, C4 +2.7 %, material_hdr(1) +2.9 %.
+    uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (FEAT != 0) {
+        constexpr uint32_t kCls = RT_SORT_CLASSES;
+        __shared__ uint32_t s_cls[4][kCls];
+        __shared__ uint16_t s_perm[256];
+        uint32_t key = kCls - 1u;
+        if (slot < n_active) {
+            const uint32_t fl0 = in.flags[slot];
+            if (!(fl0 & kDead)) {
+                if (fl0 & kFoldOnly)
+                    key = kCls - 2u;
+                else if (in.hit_prim[slot] < 0)
+                    key = kCls - 3u;
+                else
+                {
+                    const uint32_t hs0 = in.hit_slot[slot];
+                    if (hs0 & kLeafOther)
+                        key = kCls - 4u;
+                    else  // mesh hit: with more than five classes also by material (two dragons of different materials)
+                        key = kCls > 5u ? (sc.leaf_meta[hs0].mat_flags & kMetaMatMask) % (kCls - 4u) : 0u;
+                }
+            }
+        }
+        uint32_t rank = 0;
+        const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+        for (uint32_t c = 0; c < kCls; c++) {
+            const unsigned long long m = __ballot(key == c);
+            if (key == c) rank = (uint32_t)__popcll(m & below);
+            if (lane == 0) s_cls[wave][c] = (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+        uint32_t dest = rank;
+#pragma unroll
+        for (uint32_t c = 0; c < kCls; c++) {
+#pragma unroll
+            for (uint32_t w = 0; w < 4u; w++) {
+                const uint32_t cnt = s_cls[w][c];
+                if (c < key || (c == key && w < wave)) dest += cnt;
+            }
+        }
+        s_perm[dest] = (uint16_t)threadIdx.x;
+        __syncthreads();
+        slot = blockIdx.x * blockDim.x + s_perm[threadIdx.x];
+    }
     ShadeA a;
     RT_PROF_DECL
     shade_a<FEAT>(sc, in, slot, slot < n_active, max_depth, a RT_PROF_PASS);
