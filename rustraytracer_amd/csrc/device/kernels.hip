@@ -66,6 +66,17 @@ RTD void st3(double* x, double* y, double* z, uint32_t i, D3 v) {
     z[i] = v.z;
 }
 
+// Wave-uniform fetch-and-add on the SCALAR memory path (s_atomic_add, gfx9 family incl. gfx950; checked against
+// vector atomics on the same word by tools/experiments/satomic_test.hip).  Its return travels through lgkmcnt, so
+// the wave does not wait for its vector stores in flight (a vector atomic's return shares vmcnt with them and comes
+// back in order behind them).  Executes once per wave whatever EXEC is: call it from wave-uniform control flow only.
+// Not for the per-block counters of k_shade: there the scalar path is slower (C2 +8 % frame time) -- many more
+// atomics per launch on one word, and their return was not what the block waits for.
+RTD uint32_t wave_atomic_add(uint32_t* p, uint32_t v) {
+    uint32_t ret = __builtin_amdgcn_readfirstlane(v);
+    asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(ret) : "s"(p) : "memory");
+    return ret;
+}
 // wave-level compaction: lanes with pred append `value` to out[]; one atomic per wave
 RTD void wave_append(bool pred, uint32_t value, uint32_t* out, uint32_t* counter) {
     const unsigned long long mask = __ballot(pred);
@@ -272,9 +283,8 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
         }
         if (!exhausted && (n_idle >= tune.refill_lanes)) {
             if (res_next >= res_end) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&ctl->head[it], reserve);
-                base = __shfl(base, 0, 64);
+                // (scalar atomic: its return does not wait behind the result stores issued just above; 2 % of the kernel)
+                const uint32_t base = wave_atomic_add(&ctl->head[it], reserve);
                 res_next = base;
                 res_end = base + reserve < n ? base + reserve : n;
                 if (base >= n) {
