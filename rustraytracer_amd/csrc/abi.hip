@@ -78,7 +78,7 @@ struct rt_context {
     size_t pix_capacity = 0;
     std::vector<hipEvent_t> events;
     TraceTune tune{24, 4, 0, 128};
-    uint32_t tail_paths = 393216;  // switch to the fused tail kernel at or below this many live paths
+    uint32_t tail_paths = 786432;  // switch to the fused tail kernel at or below this many live paths
 };
 
 struct rt_scene {
@@ -593,7 +593,7 @@ static int lane_fail(Lane& ln, int code, const char* fmt, ...) {
 
 typedef void (*ShadeKernel)(DevScene, PathState, PathState, Ctl*, uint32_t, uint32_t, uint32_t*, double*, double*, double*,
                             DevStats*);
-typedef void (*TailKernel)(DevScene, PathState, PathState, const Ctl*, uint32_t, uint32_t, double*, double*, double*,
+typedef void (*TailKernel)(DevScene, PathState, PathState, Ctl*, uint32_t, uint32_t, double*, double*, double*,
                            DevStats*);
 static ShadeKernel shade_kernel(int v) {
     switch (v) {
@@ -670,7 +670,8 @@ static int run_lane(RenderJob& job, int lane_id) {
                 if (live <= c->tail_paths) {
                     // few paths left: one fused launch finishes them (k_tail) instead of ~2 launches per bounce
                     // that are each as slow as their single longest ray
-                    hipLaunchKernelGGL(tail_kernel(job.s->shade_variant), dim3((live + 255) / 256), dim3(256), 0, stream, job.s->dev, ln.st[0],
+                                        const uint32_t tail_blocks = std::min((live + 255) / 256, (uint32_t)c->num_cus * 2u);  // persistent waves
+                    hipLaunchKernelGGL(tail_kernel(job.s->shade_variant), dim3(tail_blocks), dim3(256), 0, stream, job.s->dev, ln.st[0],
                                        ln.st[1], ln.ctl, (uint32_t)it, cfg->max_depth, c->lf[0], c->lf[1], c->lf[2],
                                        c->stats);
                     break;

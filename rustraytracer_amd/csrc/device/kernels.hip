@@ -809,58 +809,122 @@ __global__ __launch_bounds__(256, FEAT <= RT_SHADE4_MAXFEAT ? 4 : (feat_three_wa
 // ---------------------------------------------------------------------- tail
 // Once a lane's batch is exhausted and few paths are left, per-bounce launches are bound by the single
 // longest ray of each launch (a few hundred dependent fetches), times the remaining bounces.  k_tail
-// finishes those paths in ONE launch: each lane traces its own pending rays (shadow, probe, extension)
-// with the same closest_hit and shades with the same shade_a / shade_b, ping-ponging its slot between
-// the two state buffers, until its path retires.  Same arithmetic, same counters, no queues.
+// finishes those paths in ONE launch with the same closest_hit and the same shade_a / shade_b, ping-ponging a
+// path's slot between the two state buffers until it retires.  Same arithmetic, same counters, no queues.
+// Persistent waves with (a) path replacement: a lane whose path has retired takes the next unfinished path of the
+// list (one atomic per wave and refill), so a wave does not sit on a register allocation for the sake of its one
+// longest path; and (b) pooled rays: the pending rays of the wave's live paths (up to three each: shadow, probe,
+// extension) are listed in LDS and dealt to ALL 64 lanes, so a path's three rays are traced side by side.
+// The two state buffers alternate per bounce, wave-uniformly: new paths are taken on even passes only.
 template <int FEAT>
-__global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathState buf1, const Ctl* ctl,
+__global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathState buf1, Ctl* ctl,
                                              uint32_t it_abs, uint32_t max_depth, double* lfx, double* lfy,
                                              double* lfz, DevStats* stats) {
     __shared__ int2 lds_stack[kLdsStack * 256];
-    const uint32_t n_active = ctl->n_active[it_abs % kRing];
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= n_active) return;  // (closest_hit answers -1 for a scene without primitives)
+    __shared__ uint32_t s_job[4][192];  // per wave: slot of the path | ray kind << 30
+    __shared__ int2 s_res[4][192];      // per wave: {prim, leaf slot} found for job j
+    const uint32_t ring = it_abs % kRing;
+    const uint32_t n_active = ctl->n_active[ring];
+    uint32_t* next_path = &ctl->head[ring];  // zero at launch: no k_trace runs in the tail iteration (k_plan cleared it)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t slot = 0;
+    bool alive = false;
+    bool list_done = false;  // wave-uniform
     TravStack ts;
     ts.lds = &lds_stack[threadIdx.x];
     ts.lds_stride = 256;
     TravCount tc{0, 0, 0};
     unsigned long long n_r1 = 0, n_r2 = 0, n_r3 = 0, n_v = 0;
-    int cur = (int)(it_abs & 1u);
-    // every pass retires the path or advances it by one bounce: max_depth + 2 passes always suffice
-    for (uint32_t pass = 0; pass < max_depth + 3u; pass++) {
+    const int cur0 = (int)(it_abs & 1u);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint32_t pass = 0;; pass++) {
+        const int cur = cur0 ^ (int)(pass & 1u);
         const PathState& in = cur ? buf1 : buf0;
         const PathState& out = cur ? buf0 : buf1;
-        const uint32_t fl = in.flags[slot];
-        if (fl & kDead) break;
-        const D3 o = ld3(in.ox, in.oy, in.oz, slot);
-        double t;
-        if (fl & kHasShadow) {  // Visibility::unoccluded, hittable.rs:25-32
-            const D3 d = ld3(in.spx, in.spy, in.spz, slot) - o;
-            in.sh_prim[slot] = closest_hit<false>(sc, o + d * kSmall, d, 0.0, kInf, t, ts, &tc);
+        if (!(pass & 1u) && !list_done) {
+            const unsigned long long md = __ballot(!alive);
+            const uint32_t want = (uint32_t)__popcll(md);
+            if (want) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(next_path, want);
+                base = __shfl(base, 0, 64);
+                const uint32_t idx = base + (uint32_t)__popcll(md & below);
+                if (!alive && idx < n_active) {
+                    slot = idx;
+                    alive = true;
+                }
+                if (base + want >= n_active) list_done = true;
+            }
         }
-        if (fl & kHasProbe)
-            in.pr_prim[slot] = closest_hit<false>(sc, o, ld3(in.pdx, in.pdy, in.pdz, slot), kSmall, kInf, t, ts, &tc);
-        if (!(fl & kFoldOnly))
-            in.hit_prim[slot] = closest_hit<false>(sc, o, ld3(in.dx, in.dy, in.dz, slot), kSmall, kInf, t, ts, &tc, &in.hit_slot[slot]);
-        ShadeA a;
-        RT_PROF_DECL
-        shade_a<FEAT>(sc, in, slot, true, max_depth, a RT_PROF_PASS);
-        ShadeOut r{false, false, false, false};
-        if (a.will_shade) {
-            r = shade_b<FEAT>(sc, in, out, slot, slot, a RT_PROF_PASS);
-            n_v++;
+        // the state a path's owner lane wrote in the previous pass is read by other lanes of the wave below
+        if (pass) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        uint32_t fl = kDead;
+        if (alive) fl = in.flags[slot];
+        if (fl & kDead) alive = false;
+        if (__ballot(alive) == 0ull) {
+            if (list_done) break;
+            continue;  // (an odd pass with nothing alive: the next one refills)
         }
-        n_r1 += r.emit_ext ? 1u : 0u;
-        n_r2 += r.emit_sh ? 1u : 0u;
-        n_r3 += r.emit_pr ? 1u : 0u;
-        if (!r.keep) {
-            const uint32_t og = a.orig;
-            lfx[og] = a.L.x;
-            lfy[og] = a.L.y;
-            lfz[og] = a.L.z;
-            break;
+        const bool has_sh = alive && (fl & kHasShadow), has_pr = alive && (fl & kHasProbe);
+        const bool has_ex = alive && !(fl & kFoldOnly);
+        const unsigned long long msh = __ballot(has_sh), mpr = __ballot(has_pr), mex = __ballot(has_ex);
+        const uint32_t nsh = (uint32_t)__popcll(msh), npr = (uint32_t)__popcll(mpr), nex = (uint32_t)__popcll(mex);
+        const uint32_t jsh = (uint32_t)__popcll(msh & below), jpr = nsh + (uint32_t)__popcll(mpr & below);
+        const uint32_t jex = nsh + npr + (uint32_t)__popcll(mex & below);
+        if (has_sh) s_job[wave][jsh] = slot | (kRayShadow << 30);
+        if (has_pr) s_job[wave][jpr] = slot | (kRayProbe << 30);
+        if (has_ex) s_job[wave][jex] = slot | (kRayExt << 30);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t n_jobs = nsh + npr + nex;
+        for (uint32_t j = lane; j < n_jobs; j += 64u) {
+            const uint32_t job = s_job[wave][j];
+            const uint32_t js = job & kSlotMask, kind = job >> 30;
+            const D3 o = ld3(in.ox, in.oy, in.oz, js);
+            double t;
+            uint32_t hs = 0;
+            int32_t prim;
+            if (kind == kRayShadow) {  // Visibility::unoccluded, hittable.rs:25-32
+                const D3 d = ld3(in.spx, in.spy, in.spz, js) - o;
+                prim = closest_hit<false>(sc, o + d * kSmall, d, 0.0, kInf, t, ts, &tc);
+            } else if (kind == kRayProbe) {
+                prim = closest_hit<false>(sc, o, ld3(in.pdx, in.pdy, in.pdz, js), kSmall, kInf, t, ts, &tc);
+            } else {
+                prim = closest_hit<false>(sc, o, ld3(in.dx, in.dy, in.dz, js), kSmall, kInf, t, ts, &tc, &hs);
+            }
+            s_res[wave][j] = make_int2(prim, (int)hs);
         }
-        cur ^= 1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (has_sh) in.sh_prim[slot] = s_res[wave][jsh].x;
+        if (has_pr) in.pr_prim[slot] = s_res[wave][jpr].x;
+        if (has_ex) {
+            const int2 r = s_res[wave][jex];
+            in.hit_prim[slot] = r.x;
+            in.hit_slot[slot] = (uint32_t)r.y;
+        }
+        if (alive) {
+            ShadeA a;
+            RT_PROF_DECL
+            shade_a<FEAT>(sc, in, slot, true, max_depth, a RT_PROF_PASS);
+            ShadeOut r{false, false, false, false};
+            if (a.will_shade) {
+                r = shade_b<FEAT>(sc, in, out, slot, slot, a RT_PROF_PASS);
+                n_v++;
+            }
+            n_r1 += r.emit_ext ? 1u : 0u;
+            n_r2 += r.emit_sh ? 1u : 0u;
+            n_r3 += r.emit_pr ? 1u : 0u;
+            if (!r.keep) {
+                const uint32_t og = a.orig;
+                lfx[og] = a.L.x;
+                lfy[og] = a.L.y;
+                lfz[og] = a.L.z;
+                alive = false;
+            }
+        }
     }
     DevStats* sh = stat_shard(stats);
     if (n_r1) atomicAdd(&sh->r1, n_r1);
