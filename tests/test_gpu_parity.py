@@ -186,6 +186,29 @@ def test_chunking_and_windows_do_not_change_the_image(gpu_ctx):
     gs.close()
 
 
+def test_two_lanes_and_tail_thresholds_do_not_change_the_image(gpu_ctx, monkeypatch):
+    """Scheduling knobs of the launch schedule never touch results: two pools on two streams (RT_LANES=2, engaged
+    when a batch exceeds the pool), the fused tail taking over early (every path goes through k_tail's path
+    replacement) or never (wavefront iterations to the end)."""
+    sc = rr.cornell_box_statue(mesh_faces=20000, variant=0)
+    cfg = rr.make_cfg(96, 64, 16, seed=5)
+    gs = gpu_ctx.upload(sc)
+    base, nb, sb = gpu_ctx.render(gs, sc.camera, cfg)
+    gs.close()
+    for env, pif in ((("RT_LANES", "2"), 8192), (("RT_TAIL_PATHS", "100000000"), 0), (("RT_TAIL_PATHS", "0"), 0),
+                     (("RT_TAIL_PATHS", "100000000"), 4096)):
+        monkeypatch.setenv(*env)
+        ctx = rr.Context(0)  # the knobs are read when a context is created
+        g2 = ctx.upload(sc)
+        r, n, s = ctx.render(g2, sc.camera, rr.make_cfg(96, 64, 16, seed=5, paths_in_flight=pif))
+        assert np.array_equal(r, base) and np.array_equal(n, nb), (env, pif)
+        assert (s.rays, s.rays_extension, s.rays_shadow, s.rays_probe, s.vertices_shaded) == \
+               (sb.rays, sb.rays_extension, sb.rays_shadow, sb.rays_probe, sb.vertices_shaded), (env, pif)
+        g2.close()
+        ctx.close()
+        monkeypatch.delenv(env[0])
+
+
 def test_spp_rounding_depth_and_seed(gpu_ctx):
     sc = rr.cornell_box()
     osc = O.OracleScene(sc)
