@@ -193,7 +193,9 @@ __global__ __launch_bounds__(256) void k_generate(PathState st, rt_camera cam, C
 //     tune.refill_lanes or more lanes of the wave are idle (or all are), the idle lanes take the next
 //     queue entries (__ballot/__popcll prefix) while the others keep their state.  Entries come from a
 //     per-wave reservation of tune.reserve entries, so the single queue head sees one atomic per
-//     reservation, not per refill (same-address atomics saturate near 88/us).
+//     reservation, not per refill (same-address atomics saturate near 88/us).  A finished ray's result is written
+//     in those refill rounds, not when it finishes: loads and stores share vmcnt and return in order, so a store
+//     in flight would delay the fetch every traversal round waits for.
 //   * Every wave step is EITHER a node step OR a single-primitive step, whichever more lanes are
 //     waiting for (majority scheduling): the wave never runs the primitive code for the sake of a few
 //     lanes while the rest are walking the tree, and vice versa.
