@@ -6,15 +6,24 @@ film buffers already resident in HBM, film left on the device, then (N > 1) the 
 the per-rank films to rank 0.  Rays = R1 + R2 + R3 root closest-hit queries,
 counted by the device and identical to the CPU oracle's counters.
 
-N = 1 workload: BASELINE.json configs[1] -- Cornell box + triangle-mesh statue (procedural
-P-400k stand-in for the missing data/statue.obj), Lambertian, 512x512 @ 64 spp, max_depth 25.
-N > 1: weak scaling -- the same image at N times the samples per pixel (64*N spp), its 16x16
-tiles interleaved over the ranks (tile k -> rank k % N), so every rank keeps 512*512*64 paths;
-each rank's own tiles are packed and gathered to rank 0 over RCCL/xGMI (rustraytracer_amd/dist.py).
+Workload (every N): BASELINE.json's metric config, configs[3] = C4 -- two_dragons() with both
+dragons (glass + metal, 2 x procedural P-871k in place of the missing dragon.obj), 1920x1080 @
+1024 spp, max_depth 25, seed 0.  It fits one GPU (the scene is 0.5 GB; path state + film staging
+~40 GB of the 288 GB).
+N > 1: STRONG scaling -- the same image, its 16x16 tiles interleaved over the ranks (tile k -> rank
+k % N, rt_render_cfg.tile_rank / tile_world), every rank renders only its tiles and the own-tile
+pixels are packed and gathered to rank 0 over RCCL/xGMI (rustraytracer_amd/dist.py); the gather
+time is reported separately (`gather_ms_per_step`) and is inside the timed region.
 
-One JSON line on rank 0 with `roofline` (dominant kernel k_trace, algorithmic bytes from the
-device's traversal counters over HIP-event kernel time) and `cpu_baseline` (the oracle in
-reference-shaped mode on the host cores, bounded sample).
+One JSON line on rank 0 with
+  roofline      dominant kernel k_trace: algorithmic bytes (device traversal counters of the same kernel and
+                BVH, the fused tail launch's share subtracted) over HIP-event launch time; `traffic` = HBM bytes
+                per launch from the rocprofv3 PMC passes committed under profiles/ (null if none for this
+                workload), `hbm_frac_rocprof` the measured-HBM fraction beside the algorithmic `frac`;
+                `kernels.k_shade` = the same accounting for the shading kernel
+  cpu_baseline  the oracle in reference-shaped mode on the host cores, bounded sample (rank 0, N = 1 only)
+  extra         (N = 1) the smaller single-GPU configs C2 and C3 measured the same way, for continuity with
+                round 1's numbers
 """
 import argparse
 import json
@@ -47,18 +56,24 @@ WORKLOADS = {
     "tiny": ("cornell_box_statue", dict(mesh_faces=20000, variant=0), 128, 128, 8, "tiny smoke workload"),
 }
 
-
-def algorithmic_bytes(st, info):
-    """Bytes the traversal kernel requests (cache hits included), f64 parity layout:
-    128 B per BVH4 node fetched, 76 B per triangle tested (72 B vertices + 4 B id), 52 B per
-    sphere/rect tested (48 B parameters in the leaf slot + 4 B id), 56 B per ray (24 B origin +
-    24 B dir/target + 4 B queue entry + 4 B result)."""
-    rays = st.rays_extension + st.rays_shadow + st.rays_probe
-    return (info["node_bytes"] * st.nodes_fetched + info["tri_bytes"] * st.tris_tested +
-            info["other_bytes"] * st.others_tested + 56 * rays)
+# algorithmic bytes per shaded vertex of k_shade (f64 parity layout): 244 B path state read
+# + 244 B written + the winner's scene records (72 B vertices + 72 B normals + 8 B meta + 120 B primitive or
+# material record, SURVEY.md 8d's B_shade doubled for f64 = 272 B)
+SHADE_BYTES_PER_VERTEX = 244 + 244 + 272
 
 
-def cpu_baseline(scene, W, H, target_s=14.0):
+def trace_bytes(st, info):
+    """Bytes the traversal kernel k_trace requests (cache hits included), f64 parity layout:
+    128 B per BVH4 node fetched, 76 B per triangle tested (72 B vertices + 4 B id), 52 B per sphere/rect
+    tested (48 B parameters in the leaf slot + 4 B id), 56 B per ray (24 B origin + 24 B dir/target + 4 B
+    queue entry + 4 B result).  The rays the fused tail launch traced are not k_trace's: subtracted."""
+    rays = st.rays - st.tail_rays
+    return (info["node_bytes"] * (st.nodes_fetched - st.tail_nodes_fetched) +
+            info["tri_bytes"] * (st.tris_tested - st.tail_tris_tested) +
+            info["other_bytes"] * (st.others_tested - st.tail_others_tested) + 56 * rays), rays
+
+
+def cpu_baseline(scene, W, H, target_s=9.0):
     """Oracle, reference-shaped (exhaustive traversal, 6 threads = consts.rs:8 NUM_THREADS), on a
     bounded sample of the same workload: the full image at a reduced spp chosen for ~target_s."""
     import rustraytracer_amd as rr
@@ -95,13 +110,132 @@ def cpu_baseline(scene, W, H, target_s=14.0):
     return out
 
 
+class Bench:
+    """One workload on this rank's GPU: scene resident, film on the device."""
+
+    def __init__(self, name, rank, world, local_rank, coll_dev, paths_in_flight=0):
+        import torch
+
+        import rustraytracer_amd as rr
+        from rustraytracer_amd import dist as rd
+        self.torch, self.rr = torch, rr
+        self.name, self.rank, self.world, self.coll_dev = name, rank, world, coll_dev
+        preset, kw, self.W, self.H, self.spp, self.desc = WORKLOADS[name]
+        self.scene = rr.Scene(preset, self.W / self.H, **kw)
+        self.ctx = rr.Context(local_rank)
+        self.gs = self.ctx.upload(self.scene)
+        self.info = self.gs.info()
+        self.d_rgb = torch.zeros((self.H, self.W, 3), dtype=torch.float64, device="cuda")
+        self.d_n = torch.zeros((self.H, self.W), dtype=torch.int32, device="cuda")
+        self.pif = paths_in_flight
+        self.cfg = rr.make_cfg(self.W, self.H, self.spp, seed=0, tile_rank=rank, tile_world=world,
+                               paths_in_flight=paths_in_flight)
+        self.gather = rd.FilmGather(self.W, self.H, coll_dev) if world > 1 else None
+        self.gather_s = 0.0
+
+    def step(self):
+        torch = self.torch
+        # on torch's current stream (NULL = the null stream): the film zeroing of the next step is ordered after
+        # this step's gather kernels, and the gather sees the finished film
+        st = self.ctx.render_device(self.gs, self.scene.camera, self.cfg, self.d_rgb.data_ptr(), self.d_n.data_ptr(),
+                                    stream=torch.cuda.current_stream().cuda_stream)
+        if self.gather is not None:
+            t0 = time.perf_counter()
+            # the path's only exchange step: each rank's own tiles go straight to rank 0 (RCCL over xGMI)
+            if self.coll_dev == "cuda":
+                self.gather.gather(self.d_rgb, self.d_n)
+                torch.cuda.synchronize()
+            else:  # gloo dry run: stage through the host
+                h_rgb, h_n = self.d_rgb.cpu(), self.d_n.cpu()
+                self.gather.gather(h_rgb, h_n)
+                if self.rank == 0:
+                    self.d_rgb.copy_(h_rgb)
+                    self.d_n.copy_(h_n)
+            self.gather_s += time.perf_counter() - t0
+        return st
+
+    def counted(self):
+        """Instrumented pass (outside any timed region): the same kernels and BVH with traversal counters."""
+        cfg_c = self.rr.make_cfg(self.W, self.H, self.spp, seed=0, tile_rank=self.rank, tile_world=self.world,
+                                 paths_in_flight=self.pif, count_traversal=True)
+        st = self.ctx.render_device(self.gs, self.scene.camera, cfg_c, self.d_rgb.data_ptr(), self.d_n.data_ptr())
+        self.torch.cuda.synchronize()
+        return st
+
+    def close(self):
+        self.gs.close()
+        self.ctx.close()
+
+
+def timed(b, steps, warmup, barrier):
+    for _ in range(warmup):
+        b.step()
+    barrier()
+    b.gather_s = 0.0
+    acc = {"rays": 0, "trace_ms": 0.0, "kernel_ms": 0.0, "launches": 0, "shade_ms": 0.0, "shade_launches": 0,
+           "vertices": 0}
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st = b.step()
+        acc["rays"] += st.rays
+        acc["trace_ms"] += st.trace_ms
+        acc["kernel_ms"] += st.kernel_ms
+        acc["launches"] += st.trace_launches
+        acc["shade_ms"] += st.shade_ms
+        acc["shade_launches"] += st.shade_launches
+        acc["vertices"] += st.vertices_shaded
+    barrier()
+    acc["dt"] = time.perf_counter() - t0
+    return acc
+
+
+def roofline(b, acc, stc, steps):
+    """k_trace (dominant) and k_shade: algorithmic bytes per launch over mean HIP-event launch duration."""
+    alg, trace_rays = trace_bytes(stc, b.info)  # per render, this rank
+    launches_per_step = acc["launches"] / max(steps, 1)
+    avg_launch_s = (acc["trace_ms"] / 1e3) / max(acc["launches"], 1)
+    bytes_per_launch = alg / max(launches_per_step, 1)
+    achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+    traffic = traffic_step = frac_pmc = None
+    pmc = os.path.join(ROOT, "profiles", f"trace_pmc_{b.name}.json")
+    if b.world == 1 and os.path.exists(pmc):
+        try:
+            traffic = float(json.load(open(pmc)).get("hbm_bytes_per_launch"))
+            traffic_step = traffic * launches_per_step
+            frac_pmc = traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS
+        except Exception:
+            traffic = traffic_step = frac_pmc = None
+    sh_alg = SHADE_BYTES_PER_VERTEX * stc.vertices_shaded
+    sh_launches_per_step = acc["shade_launches"] / max(steps, 1)
+    sh_avg_s = (acc["shade_ms"] / 1e3) / max(acc["shade_launches"], 1)
+    sh_ach = sh_alg / max(sh_launches_per_step, 1) / sh_avg_s / 1e9 if sh_avg_s > 0 else 0.0
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "kernel": "k_trace", "avg_launch_ms": avg_launch_s * 1e3, "launches_per_step": launches_per_step,
+            "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_bytes_per_step": alg,
+            "traffic_per_step": traffic_step, "hbm_frac_rocprof": frac_pmc,
+            "bytes_per_ray": alg / max(trace_rays, 1),
+            "nodes_per_ray": (stc.nodes_fetched - stc.tail_nodes_fetched) / max(trace_rays, 1),
+            "tris_per_ray": (stc.tris_tested - stc.tail_tris_tested) / max(trace_rays, 1),
+            "rays_in_fused_tail_launch": stc.tail_rays,
+            "trace_share_of_device_time": acc["trace_ms"] / max(acc["kernel_ms"], 1e-9),
+            "kernels": {"k_shade": {
+                "bound": "hbm", "achieved": sh_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sh_ach / HBM_PEAK_GBS,
+                "avg_launch_ms": sh_avg_s * 1e3, "launches_per_step": sh_launches_per_step,
+                "algorithmic_bytes_per_step": sh_alg, "bytes_per_vertex": SHADE_BYTES_PER_VERTEX,
+                "share_of_device_time": acc["shade_ms"] / max(acc["kernel_ms"], 1e-9),
+                "note": "f64 VALU / latency bound, not byte bound (DESIGN.md section 4): the fraction is reported, "
+                        "not a target"}}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
+    ap.add_argument("--workload", default="c4", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the C2 / C3 rows")
     ap.add_argument("--paths-in-flight", type=int, default=0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: dry run of the N>1 control flow with several ranks sharing one GPU (films gathered on the host)")
@@ -131,112 +265,65 @@ def main():
             dist.init_process_group(backend="gloo")
     coll_dev = "cuda" if args.backend == "nccl" else "cpu"
 
-    preset, kw, W, H, spp0, desc = WORKLOADS[args.workload]
-    spp = spp0 * world  # weak scaling: N times the samples, tiles interleaved over ranks
-    scene = rr.Scene(preset, W / H, **kw)
-    ctx = rr.Context(local_rank)
-    gs = ctx.upload(scene)
-    info = gs.info()
-    d_rgb = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
-    d_n = torch.zeros((H, W), dtype=torch.int32, device="cuda")
-    cfg = rr.make_cfg(W, H, spp, seed=0, tile_rank=rank, tile_world=world, paths_in_flight=args.paths_in_flight)
-    from rustraytracer_amd import dist as rd
-    gather = rd.FilmGather(W, H, coll_dev) if world > 1 else None
-
-    def step():
-        # on torch's current stream, so that the film zeroing of the next step is ordered after this step's gather
-        st = ctx.render_device(gs, scene.camera, cfg, d_rgb.data_ptr(), d_n.data_ptr(),
-                               stream=torch.cuda.current_stream().cuda_stream)
-        if gather is not None:
-            # the path's only exchange step: each rank's own tiles go straight to rank 0 (RCCL over xGMI)
-            if coll_dev == "cuda":
-                gather.gather(d_rgb, d_n)
-            else:  # gloo dry run: stage through the host
-                h_rgb, h_n = d_rgb.cpu(), d_n.cpu()
-                gather.gather(h_rgb, h_n)
-                if rank == 0:
-                    d_rgb.copy_(h_rgb)
-                    d_n.copy_(h_n)
-        return st
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    rays = 0
-    trace_ms = 0.0
-    launches = 0
-    kernel_ms = 0.0
-    for _ in range(args.steps):
-        st = step()
-        rays += st.rays
-        trace_ms += st.trace_ms
-        kernel_ms += st.kernel_ms
-        launches += st.trace_launches
-    barrier()
-    dt = time.perf_counter() - t0
+    b = Bench(args.workload, rank, world, local_rank, coll_dev, args.paths_in_flight)
+    acc = timed(b, args.steps, args.warmup, barrier)
     # max over ranks of the elapsed time, sum of rays
-    tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-    rr_ = torch.tensor([float(rays)], dtype=torch.float64, device=coll_dev)
+    tt = torch.tensor([acc["dt"], b.gather_s], dtype=torch.float64, device=coll_dev)
+    rr_ = torch.tensor([float(acc["rays"])], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(rr_, op=dist.ReduceOp.SUM)
-    dt_max, rays_all = float(tt.item()), float(rr_.item())
-
-    # instrumented pass (outside the timed region): the same kernel and BVH with traversal counters
-    cfg_c = rr.make_cfg(W, H, spp, seed=0, tile_rank=rank, tile_world=world, paths_in_flight=args.paths_in_flight,
-                        count_traversal=True)
-    stc = ctx.render_device(gs, scene.camera, cfg_c, d_rgb.data_ptr(), d_n.data_ptr())
-    torch.cuda.synchronize()
+    dt_max, gather_max, rays_all = float(tt[0].item()), float(tt[1].item()), float(rr_.item())
+    stc = b.counted()
 
     if rank == 0:
-        alg = algorithmic_bytes(stc, info)  # per render, this rank
-        avg_launch_s = (trace_ms / 1e3) / max(launches, 1)
-        launches_per_render = launches / max(args.steps, 1)
-        bytes_per_launch = alg / max(launches_per_render, 1)
-        achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", f"trace_pmc_{args.workload}.json")
-        if world == 1 and os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        W, H, spp = b.W, b.H, b.spp
         out = {
             "metric": "Mrays/sec (primary+secondary)", "value": rays_all / dt_max / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": desc + (f"; weak scaling: {spp} spp, 16x16 tiles interleaved over {world} ranks, "
-                                            "own tiles gathered to rank 0 over RCCL" if world > 1 else ""),
+            "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": b.desc + (f"; strong scaling: the same image, 16x16 tiles interleaved over {world} "
+                                              "ranks, own tiles gathered to rank 0 over RCCL" if world > 1 else ""),
                        "width": W, "height": H, "spp": spp, "max_depth": rr.MAX_DEPTH, "seed": 0,
-                       "triangles": info["n_triangles"], "bvh_nodes": info["n_bvh_nodes"],
+                       "triangles": b.info["n_triangles"], "bvh_nodes": b.info["n_bvh_nodes"],
                        "rays_per_step": rays_all / args.steps, "paths_per_step": W * H * spp,
                        "parallelism": f"tiles{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_trace", "avg_launch_ms": avg_launch_s * 1e3,
-                         "launches_per_step": launches_per_render,
-                         "algorithmic_bytes_per_step": alg,
-                         "bytes_per_ray": alg / max(stc.rays, 1),
-                         "nodes_per_ray": stc.nodes_fetched / max(stc.rays, 1),
-                         "tris_per_ray": stc.tris_tested / max(stc.rays, 1),
-                         "trace_share_of_device_time": trace_ms / max(kernel_ms, 1e-9)},
-            "device_ms_per_step": kernel_ms / args.steps,
+            "roofline": roofline(b, acc, stc, args.steps),
+            "device_ms_per_step": acc["kernel_ms"] / args.steps,
+            "gather_ms_per_step": gather_max / args.steps * 1e3 if world > 1 else 0.0,
             # also paths/s and the mean path length (rays per camera sample), whole job
             "mpaths_per_s": W * H * spp * args.steps / dt_max / 1e6,
             "mean_rays_per_path": rays_all / args.steps / (W * H * spp),
         }
+        scene_for_cpu = b.scene
+    b_main = b
+    if world == 1 and not args.no_extra and args.workload == "c4":
+        # the smaller single-GPU configs, same accounting (they are parity-test cases, not the headline)
+        extra = []
+        for name in ("c2", "c3"):
+            e = Bench(name, 0, 1, local_rank, coll_dev, args.paths_in_flight)
+            ea = timed(e, 2 if name == "c3" else 5, 1, barrier)
+            esteps = 2 if name == "c3" else 5
+            ec = e.counted()
+            rf = roofline(e, ea, ec, esteps)
+            extra.append({"workload": e.desc, "value": ea["rays"] / ea["dt"] / 1e6, "unit": "Mrays/s",
+                          "ms_per_step": ea["dt"] / esteps * 1e3, "steps": esteps,
+                          "roofline": {k: rf[k] for k in ("achieved", "frac", "traffic", "hbm_frac_rocprof",
+                                                          "avg_launch_ms", "launches_per_step", "bytes_per_ray")},
+                          "k_shade_ms_per_step": ea["shade_ms"] / esteps, "k_trace_ms_per_step": ea["trace_ms"] / esteps})
+            e.close()
+        out["extra"] = extra
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, W, H)
+            out["cpu_baseline"] = cpu_baseline(scene_for_cpu, b_main.W, b_main.H)
         print(json.dumps(out), flush=True)
-    gs.close()
-    ctx.close()
+    b_main.close()
     if world > 1:
         dist.destroy_process_group()
 

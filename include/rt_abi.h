@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 
 /* ---------------------------------------------------------------- status */
 typedef enum rt_status {
@@ -49,7 +49,10 @@ typedef enum rt_status {
     RT_ERR_HIP = -3,         /* a HIP runtime call failed (see rt_last_error)  */
     RT_ERR_UNSUPPORTED = -4, /* valid but outside the hot-path scope           */
     RT_ERR_STATE = -5,       /* call order violated (e.g. render before commit)*/
-    RT_ERR_OOM = -6          /* host or device allocation failed               */
+    RT_ERR_OOM = -6,         /* host or device allocation failed               */
+    RT_ERR_CANCELLED = -7    /* rt_render_cfg.cancel became non-zero; the film is
+                                incomplete (the reference's stop_render poll,
+                                render.rs:93)                                   */
 } rt_status;
 
 /* ------------------------------------------------------------- constants */
@@ -225,6 +228,10 @@ typedef struct rt_render_cfg {
      * Sample k of a pixel is the same path whichever pass renders it.          */
     uint32_t sample_first;
     uint32_t sample_count;
+    /* Optional cancellation flag (NULL = none), the counterpart of GLOBAL_STATE.stop_render that the
+     * reference's workers poll per pixel (render.rs:93, main.rs:315-321).  The library polls it between
+     * kernel launches; once it reads non-zero the call drains the device and returns RT_ERR_CANCELLED.  */
+    const volatile int32_t* cancel;
 } rt_render_cfg;
 
 #define RT_RENDER_COUNT_TRAVERSAL 1u /* fill the node/prim test counters       */
@@ -247,7 +254,21 @@ typedef struct rt_stats {
     double kernel_ms;          /* all device work of this call (HIP events)    */
     double trace_ms;           /* traversal kernel only (HIP events)           */
     uint64_t trace_launches;
-    uint64_t reserved[4];
+    /* The last few paths of a batch are finished by one fused launch (k_tail) instead of per-bounce
+     * launches.  rays_* and, with RT_RENDER_COUNT_TRAVERSAL, nodes_fetched / tris_tested / others_tested
+     * cover ALL rays; the four fields below are the fused launch's share, so that
+     * (total - tail) is exactly what the traversal kernel timed by trace_ms processed.                 */
+    uint64_t tail_rays;
+    uint64_t tail_nodes_fetched;
+    uint64_t tail_tris_tested;
+    uint64_t tail_others_tested;
+    /* Multi-device contexts: counters are summed over the devices, kernel_ms is the slowest device's
+     * (they run side by side), trace_ms / trace_launches are summed (their ratio stays the mean launch
+     * time), gather_ms is the host-clock time of the final peer-to-peer film gather.                   */
+    double gather_ms;
+    uint64_t n_devices;
+    double shade_ms;           /* shading kernel only (HIP events), like trace_ms */
+    uint64_t shade_launches;
 } rt_stats;
 
 typedef struct rt_ray {
@@ -266,8 +287,14 @@ typedef struct rt_hit {
 typedef struct rt_context rt_context;
 typedef struct rt_scene rt_scene;
 
-/* One context per process and GPU.  device_ids may be NULL (device 0);
- * n_devices must be 1 in this version (multi-GPU = one process per GPU).      */
+/* device_ids may be NULL with n_devices == 0 (device 0).  With n_devices > 1 the
+ * context spans several GPUs of one node: scenes are
+ * replicated at commit, rt_render / rt_render_device run one host thread per
+ * device on interleaved tiles and gather the film onto device_ids[0] with
+ * direct peer-to-peer copies; the film pointers of rt_render_device live on
+ * device_ids[0].  The result is bit-identical to a one-device render.  (The
+ * alternative, one process per GPU with its own one-device context and
+ * rt_render_cfg.tile_rank / tile_world, is what bench.py uses.)               */
 int rt_context_create(const int* device_ids, int n_devices, rt_context** out);
 int rt_context_destroy(rt_context* ctx);
 
@@ -310,7 +337,12 @@ int rt_scene_get_info(const rt_scene* s, rt_scene_info* out);
 int rt_render(rt_context* ctx, rt_scene* s, const rt_camera* cam, const rt_render_cfg* cfg,
               double* rgb_sum, uint32_t* n, rt_stats* stats);
 /* Same, writing into caller-owned DEVICE buffers (W*H*3 doubles, W*H u32),
- * zeroed by the call, on `hip_stream` (a hipStream_t, may be NULL).           */
+ * zeroed by the call.  Everything that touches the film (zeroing, the resolve
+ * of each batch) is enqueued on `hip_stream`, a hipStream_t; NULL is the
+ * default (null) stream, exactly as in any HIP call -- so work the caller
+ * queued on that stream before the call happens before the film is touched and
+ * work queued on it afterwards sees the finished film.  The call returns after
+ * the film is complete (it synchronises `hip_stream`).                         */
 int rt_render_device(rt_context* ctx, rt_scene* s, const rt_camera* cam, const rt_render_cfg* cfg,
                      double* d_rgb_sum, uint32_t* d_n, void* hip_stream, rt_stats* stats);
 

@@ -14,8 +14,8 @@
  * nothing but IEEE +,-,*,/,sqrt and integer bit moves, so that gcc on the host
  * and hipcc on gfx950 produce bit-identical results when FP contraction is
  * off (-ffp-contract=off is mandatory for every translation unit including
- * this header).  tests/test_detmath.py bounds the distance to libm (<= 1 ulp
- * observed for sin/cos/log/atan2/acos on the domains the path uses).
+ * this header).  tests/test_host_cpu.py::test_detmath_close_to_libm bounds the distance to libm (<= 2 ulp;
+ * <= 1 ulp observed for sin/cos/log/atan2/acos on the domains the path uses).
  */
 #ifndef RT_DETMATH_H
 #define RT_DETMATH_H

@@ -1811,6 +1811,46 @@ void oracle_micro_trans(double ax, double ay, double eta, const double* color, c
     s_wi[0] = swi.x; s_wi[1] = swi.y; s_wi[2] = swi.z;
     s_f[0] = sf.x; s_f[1] = sf.y; s_f[2] = sf.z;
 }
+// Generic single-lobe entry points for the independent value tables (tests/golden/lobe_tables.json, made by
+// tools/make_lobe_tables.py with mpmath straight from bxdf.rs / microfacet.rs): local-frame f + pdf, and one
+// sample_f draw.  `rng_key` = (seed, pixel, sample) of the counter stream that feeds default_sample_f's two
+// entropy draws (Lambert only).
+static Lobe lobe_from_desc(const oracle_lobe* d) {
+    Lobe l;
+    l.kind = d->kind;
+    l.fresnel = d->fresnel;
+    l.color = v3(d->color[0], d->color[1], d->color[2]);
+    l.t = v3(d->t[0], d->t[1], d->t[2]);
+    l.eta_i = d->eta_i; l.eta_t = d->eta_t;
+    l.eta = v3(d->eta[0], d->eta[1], d->eta[2]);
+    l.k = v3(d->k[0], d->k[1], d->k[2]);
+    l.alpha_x = d->alpha_x; l.alpha_y = d->alpha_y;
+    l.eta_a = d->eta_a; l.eta_b = d->eta_b;
+    switch (d->kind) {
+        case LOBE_LAMBERT: l.type = RT_BSDF_REFLECTION | RT_BSDF_DIFFUSE; break;
+        case LOBE_MICROFACET: l.type = RT_BSDF_REFLECTION | RT_BSDF_GLOSSY; break;
+        case LOBE_FRESNEL_SPECULAR: l.type = RT_BSDF_REFLECTION | RT_BSDF_TRANSMISSION | RT_BSDF_SPECULAR; break;
+        case LOBE_SPECULAR_REFL: l.type = RT_BSDF_REFLECTION | RT_BSDF_SPECULAR; break;
+        default: l.type = RT_BSDF_TRANSMISSION | RT_BSDF_GLOSSY; break;
+    }
+    return l;
+}
+void oracle_lobe_eval(const oracle_lobe* d, const double* wo, const double* wi, double* f, double* pdf) {
+    const Lobe l = lobe_from_desc(d);
+    const V3 o = v3(wo[0], wo[1], wo[2]), i = v3(wi[0], wi[1], wi[2]);
+    const V3 r = bxdf_f(l, o, i);
+    f[0] = r.x; f[1] = r.y; f[2] = r.z;
+    *pdf = bxdf_pdf(l, o, i);
+}
+void oracle_lobe_sample(const oracle_lobe* d, const double* wo, double u0, double u1, const uint64_t* rng_key,
+                        double* f, double* wi, double* pdf) {
+    const Lobe l = lobe_from_desc(d);
+    Rng rng(rng_key[0], rng_key[1], rng_key[2]);
+    V3 sf, swi;
+    bxdf_sample_f(l, v3(wo[0], wo[1], wo[2]), u0, u1, rng, sf, swi, *pdf);
+    f[0] = sf.x; f[1] = sf.y; f[2] = sf.z;
+    wi[0] = swi.x; wi[1] = swi.y; wi[2] = swi.z;
+}
 // Light::Infinite of the scene (next-row f4).  what: 0 sample (in = u0,u1; out = uv0, uv1, map_pdf),
 // 1 map pdf at (in = p0,p1), 2 le(dir), 3 pdf_li(dir), 4 table sizes (out = nu, nv, marg_int)
 int oracle_env(const oracle_scene* s, int what, const double* in, double* out) {

@@ -60,6 +60,21 @@ void oracle_microfacet_f_pdf(double ax, double ay, const double* eta, const doub
                              const double* wi, double* f, double* pdf);
 void oracle_micro_trans(double ax, double ay, double eta, const double* color, const double* wo, const double* wi,
                         double u0, double u1, double* f, double* pdf, double* s_wi, double* s_f, double* s_pdf);
+/* One BxDF lobe in the local shading frame.  kind: 0 LambertianReflection, 1 MicrofacetReflection
+ * (Trowbridge-Reitz, visible-area sampling), 2 FresnelSpecular, 3 SpecularReflection,
+ * 4 MicrofacetTransmission; fresnel: 0 FresnelDielectric{eta_i, eta_t}, 1 FresnelConductor{eta, k},
+ * 2 FresnelNoOp.  alpha_x / alpha_y are the values AFTER make_trowbridge_reitz's max(1e-3) clamp.   */
+typedef struct oracle_lobe {
+    int32_t kind, fresnel;
+    double color[3], t[3];
+    double eta_i, eta_t;
+    double eta[3], k[3];
+    double alpha_x, alpha_y;
+    double eta_a, eta_b;
+} oracle_lobe;
+void oracle_lobe_eval(const oracle_lobe* lobe, const double* wo, const double* wi, double* f, double* pdf);
+void oracle_lobe_sample(const oracle_lobe* lobe, const double* wo, double u0, double u1, const uint64_t* rng_key,
+                        double* f, double* wi, double* pdf);
 int oracle_env(const oracle_scene* s, int what, const double* in, double* out);
 double oracle_prim_area(const oracle_scene* s, int32_t prim);
 double oracle_prim_pdf(const oracle_scene* s, int32_t prim, const double* p, const double* dir);

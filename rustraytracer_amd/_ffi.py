@@ -17,6 +17,8 @@ RT_ERR_HIP = -3
 RT_ERR_UNSUPPORTED = -4
 RT_ERR_STATE = -5
 RT_ERR_OOM = -6
+RT_ERR_CANCELLED = -7
+RT_PRECISION_F64, RT_PRECISION_F32 = 0, 1
 
 RT_PRIM_SPHERE, RT_PRIM_TRIANGLE, RT_PRIM_XY_RECT, RT_PRIM_XZ_RECT, RT_PRIM_YZ_RECT = range(5)
 RT_TEX_SOLID, RT_TEX_CHECKERED = 0, 1
@@ -94,6 +96,7 @@ class rt_render_cfg(C.Structure):
         ("tile_size", C.c_uint32), ("tile_rank", C.c_uint32), ("tile_world", C.c_uint32),
         ("precision", C.c_uint32), ("paths_in_flight", C.c_uint32), ("flags", C.c_uint32),
         ("sample_first", C.c_uint32), ("sample_count", C.c_uint32),
+        ("cancel", C.POINTER(C.c_int32)),
     ]
 
 
@@ -103,11 +106,14 @@ class rt_stats(C.Structure):
         ("rays_probe", C.c_uint64), ("vertices_shaded", C.c_uint64), ("nodes_fetched", C.c_uint64),
         ("tris_tested", C.c_uint64), ("others_tested", C.c_uint64),
         ("kernel_ms", C.c_double), ("trace_ms", C.c_double), ("trace_launches", C.c_uint64),
-        ("reserved", C.c_uint64 * 4),
+        ("tail_rays", C.c_uint64), ("tail_nodes_fetched", C.c_uint64), ("tail_tris_tested", C.c_uint64),
+        ("tail_others_tested", C.c_uint64),
+        ("gather_ms", C.c_double), ("n_devices", C.c_uint64),
+        ("shade_ms", C.c_double), ("shade_launches", C.c_uint64),
     ]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
     @property
     def rays(self):

@@ -65,14 +65,17 @@ class Scene:
 
 
 def make_cfg(width, height, spp, max_depth=MAX_DEPTH, seed=0, window=None, tile_rank=0, tile_world=1,
-             paths_in_flight=0, count_traversal=False, sample_first=0, sample_count=0, accumulate=False):
+             paths_in_flight=0, count_traversal=False, sample_first=0, sample_count=0, accumulate=False, cancel=None,
+             precision=0):
     cfg = F.rt_render_cfg()
     cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed = width, height, spp, max_depth, seed
     if window:
         cfg.x0, cfg.y0, cfg.x1, cfg.y1 = window
     cfg.tile_size = TILE_SIZE
     cfg.tile_rank, cfg.tile_world = tile_rank, tile_world
-    cfg.precision = 0
+    cfg.precision = precision  # F.RT_PRECISION_F64 (parity mode) / F.RT_PRECISION_F32 (fast mode)
+    if cancel is not None:  # a ctypes c_int32 the caller may set from another thread (render.rs:93 stop_render)
+        cfg.cancel = C.pointer(cancel)
     cfg.paths_in_flight = paths_in_flight
     cfg.flags = (F.RT_RENDER_COUNT_TRAVERSAL if count_traversal else 0) | (F.RT_RENDER_ACCUMULATE if accumulate else 0)
     cfg.sample_first, cfg.sample_count = sample_first, sample_count  # progressive pass (0, 0 = every sample)
@@ -99,15 +102,17 @@ class GpuScene:
 
 
 class Context:
-    """One per process and GPU (rt_context)."""
+    """rt_context: one device (an int) or several GPUs of the node (a list of device ids; films live on the first)."""
 
     def __init__(self, device=0):
         L = F.lib()
         h = C.c_void_p()
-        dev = (C.c_int * 1)(device)
-        _check(L.rt_context_create(dev, 1, C.byref(h)))
+        ids = list(device) if isinstance(device, (list, tuple)) else [device]
+        dev = (C.c_int * len(ids))(*ids)
+        _check(L.rt_context_create(dev, len(ids), C.byref(h)))
         self._h = h
-        self.device = device
+        self.device = ids[0]
+        self.devices = ids
 
     def upload(self, scene, device_build=False):
         """rt_scene_create + set_* + rt_scene_commit_ex; device_build=True builds the BVH on the GPU (row f3)."""

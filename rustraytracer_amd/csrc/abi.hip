@@ -57,8 +57,8 @@ struct Lane {
     std::vector<hipEvent_t> events;
     size_t ev_i = 0;
     // per-render results of this lane
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_ev;
-    uint64_t trace_launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_ev, shade_ev;
+    uint64_t trace_launches = 0, shade_launches = 0;
     int rc = RT_OK;
     char err[512] = "";
 };
@@ -79,6 +79,22 @@ struct rt_context {
     std::vector<hipEvent_t> events;
     TraceTune tune{24, 4, 0, 128};
     uint32_t tail_paths = 786432;  // switch to the fused tail kernel at or below this many live paths
+    std::vector<uint32_t> last_pix;  // pixel list of the last render on this context (host copy, for the gather)
+    // ---- multi-device contexts (rt_context_create with n_devices > 1)
+    // The primary context owns one single-device context per further device.  rt_render splits the caller's tiles
+    // over all of them (one host thread per device), and each peer's own pixels are packed, copied peer-to-peer
+    // to the primary device and scattered into the caller's film.
+    std::vector<rt_context*> peers;
+    double* pf_rgb = nullptr;   // as a peer: scratch film on this device
+    uint32_t* pf_n = nullptr;
+    size_t pf_cap = 0;
+    double* pack = nullptr;     // as a peer: own pixels packed as {r, g, b, n} doubles
+    size_t pack_cap = 0;
+    double* stage = nullptr;    // as the primary: landing buffer of the peers' payloads, one after the other
+    size_t stage_cap = 0;
+    uint32_t* stage_pix = nullptr;  // ... and their pixel lists
+    size_t stage_pix_cap = 0;
+    hipEvent_t ev_gather = nullptr;
 };
 
 struct rt_scene {
@@ -101,6 +117,7 @@ struct rt_scene {
     std::vector<void*> allocs;
     DevScene dev{};
     rt_scene_info info{};
+    std::vector<rt_scene*> replicas;  // multi-device context: the device copies on ctx->peers[i] (no host data)
 };
 
 static int ensure_lane_capacity(rt_context* c, Lane& ln, uint32_t cap) {
@@ -152,6 +169,8 @@ static int upload(rt_scene* s, const T* host, size_t count, const T** dev) {
     return RT_OK;
 }
 
+static int context_init(rt_context* c);
+
 extern "C" {
 
 const char* rt_last_error(void) { return g_err; }
@@ -160,16 +179,48 @@ int rt_abi_version(void) { return RT_ABI_VERSION; }
 int rt_context_create(const int* device_ids, int n_devices, rt_context** out) {
     if (!out) return fail(RT_ERR_INVALID_ARG, "rt_context_create: out is null");
     *out = nullptr;
-    if (n_devices < 0 || n_devices > 1)
-        return fail(RT_ERR_UNSUPPORTED, "rt_context_create: one device per context (one process per GPU)");
+    if (n_devices < 0 || n_devices > 64) return fail(RT_ERR_INVALID_ARG, "rt_context_create: n_devices out of range");
+    if (n_devices > 0 && !device_ids) return fail(RT_ERR_INVALID_ARG, "rt_context_create: device_ids is null");
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device: %s", hipGetErrorString(e));
-    int dev = (device_ids && n_devices == 1) ? device_ids[0] : 0;
-    if (dev < 0 || dev >= count) return fail(RT_ERR_NO_DEVICE, "device %d out of range (%d devices)", dev, count);
+    int dev = n_devices >= 1 ? device_ids[0] : 0;
+    for (int i = 0; i < n_devices; i++)
+        if (device_ids[i] < 0 || device_ids[i] >= count)
+            return fail(RT_ERR_NO_DEVICE, "device %d out of range (%d devices)", device_ids[i], count);
     rt_context* c = new (std::nothrow) rt_context();
     if (!c) return fail(RT_ERR_OOM, "host allocation failed");
     c->device = dev;
+    int rc = context_init(c);
+    // further devices: one single-device context each (a device id may repeat: two contexts then share that GPU,
+    // which is how the multi-device path is exercised on a one-GPU box)
+    for (int i = 1; rc == RT_OK && i < n_devices; i++) {
+        rt_context* p = nullptr;
+        rc = rt_context_create(&device_ids[i], 1, &p);
+        if (rc != RT_OK) break;
+        c->peers.push_back(p);
+        if (p->device != c->device) {  // direct peer-to-peer copies over xGMI where the platform allows them
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, c->device, p->device) == hipSuccess && can) {
+                (void)hipSetDevice(c->device);
+                hipError_t pe = hipDeviceEnablePeerAccess(p->device, 0);
+                if (pe != hipSuccess) (void)hipGetLastError();  // already enabled / unsupported: hipMemcpyPeer still works
+                (void)hipSetDevice(p->device);
+                pe = hipDeviceEnablePeerAccess(c->device, 0);
+                if (pe != hipSuccess) (void)hipGetLastError();
+            }
+        }
+    }
+    if (rc != RT_OK) {
+        rt_context_destroy(c);  // tolerates partially initialised members; g_err keeps the cause
+        return rc;
+    }
+    *out = c;
+    return RT_OK;
+}
+
+static int context_init(rt_context* c) {
+    const int dev = c->device;
     HIP_TRY(hipSetDevice(dev));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, dev));
@@ -190,13 +241,19 @@ int rt_context_create(const int* device_ids, int n_devices, rt_context** out) {
     }
     HIP_TRY(hipMalloc((void**)&c->stats, sizeof(DevStats) * kStatShards));
     HIP_TRY(hipMalloc((void**)&c->batch, sizeof(BatchCtl)));
-    *out = c;
     return RT_OK;
 }
 
 int rt_context_destroy(rt_context* c) {
     if (!c) return RT_OK;
+    for (rt_context* p : c->peers) (void)rt_context_destroy(p);
     (void)hipSetDevice(c->device);
+    if (c->pf_rgb) (void)hipFree(c->pf_rgb);
+    if (c->pf_n) (void)hipFree(c->pf_n);
+    if (c->pack) (void)hipFree(c->pack);
+    if (c->stage) (void)hipFree(c->stage);
+    if (c->stage_pix) (void)hipFree(c->stage_pix);
+    if (c->ev_gather) (void)hipEventDestroy(c->ev_gather);
     for (auto ev : c->events) (void)hipEventDestroy(ev);
     for (int i = 0; i < kLanes; i++) {
         Lane& ln = c->lanes[i];
@@ -220,6 +277,15 @@ int rt_scene_create(rt_context* ctx, rt_scene** out) {
     rt_scene* s = new (std::nothrow) rt_scene();
     if (!s) return fail(RT_ERR_OOM, "host allocation failed");
     s->ctx = ctx;
+    for (rt_context* p : ctx->peers) {  // device copies for the other devices; filled by rt_scene_commit
+        rt_scene* r = new (std::nothrow) rt_scene();
+        if (!r) {
+            rt_scene_destroy(s);
+            return fail(RT_ERR_OOM, "host allocation failed");
+        }
+        r->ctx = p;
+        s->replicas.push_back(r);
+    }
     *out = s;
     return RT_OK;
 }
@@ -255,7 +321,9 @@ int rt_scene_set_meshes(rt_scene* s, const rt_mesh* meshes, uint64_t count) {
 int rt_scene_set_primitives(rt_scene* s, const rt_primitive* prims, uint64_t count) {
     SCENE_MUTABLE(s);
     if (count && !prims) return fail(RT_ERR_INVALID_ARG, "prims is null");
-    if (count >= (1ull << 28)) return fail(RT_ERR_UNSUPPORTED, "too many primitives");
+    // a leaf code is (first_slot * 8 + count - 1) | kLeafCodeOther (scene_dev.h): slots must stay below bit 27
+    static_assert((((uint64_t)kMaxPrims - 1) * 8 + 7) < (uint64_t)kLeafCodeOther, "leaf code layout");
+    if (count >= kMaxPrims) return fail(RT_ERR_UNSUPPORTED, "too many primitives (limit 2^27 - 1)");
     s->prims.assign(prims, prims + count);
     return RT_OK;
 }
@@ -361,30 +429,54 @@ static int validate_scene(const rt_scene* s) {
 
 int rt_scene_commit(rt_scene* s) { return rt_scene_commit_ex(s, RT_COMMIT_HOST_SAH); }
 
+// What the host builder produces, kept so that the replicas of a multi-device context upload the same arrays
+// instead of building the tree again.
+struct HostLeafData {
+    bool valid = false;
+    std::vector<DevNode> nodes;
+    std::vector<uint32_t> leaf_prim;
+    std::vector<double> leaf_tri, leaf_nrm;
+    std::vector<LeafMeta> leaf_meta;
+    uint32_t depth = 0;
+    uint64_t n_tri = 0;
+};
+static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cache);
+
 int rt_scene_commit_ex(rt_scene* s, uint32_t flags) {
     SCENE_MUTABLE(s);
     if (flags & ~(uint32_t)RT_COMMIT_DEVICE_LBVH) return fail(RT_ERR_INVALID_ARG, "unknown commit flags 0x%x", flags);
     int rc = validate_scene(s);
     if (rc != RT_OK) return rc;
-    HIP_TRY(hipSetDevice(s->ctx->device));
+    HostLeafData cache;
+    if ((rc = commit_to(s, s, flags, cache)) != RT_OK) return rc;
+    // multi-device context: the scene is replicated on every device, same arrays, same tree
+    for (rt_scene* r : s->replicas)
+        if ((rc = commit_to(s, r, flags, cache)) != RT_OK) return rc;
+    return RT_OK;
+}
+
+// Uploads the scene held (on the host) by `s` to the device of `t` (t == s for the primary copy).
+static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cache) {
+    int rc = RT_OK;
+    HIP_TRY(hipSetDevice(t->ctx->device));
     const size_t np = s->prims.size();
-    s->info = rt_scene_info{};
-    DevScene& d = s->dev;
+    t->info = rt_scene_info{};
+    DevScene& d = t->dev;
     d = DevScene{};
     // records the builders and the kernels read
-    if ((rc = upload(s, s->prims.data(), s->prims.size(), &d.prims)) != RT_OK) return rc;
+    if ((rc = upload(t, s->prims.data(), s->prims.size(), &d.prims)) != RT_OK) return rc;
     std::vector<DevMesh> dm(s->meshes.size());
     uint32_t has_uv = 0;
     for (size_t i = 0; i < s->meshes.size(); i++) {
         auto& m = s->meshes[i];
-        if ((rc = upload(s, m.p.data(), m.p.size(), &dm[i].p)) != RT_OK) return rc;
-        if ((rc = upload(s, m.n.data(), m.n.size(), &dm[i].n)) != RT_OK) return rc;
-        if ((rc = upload(s, m.uv.data(), m.uv.size(), &dm[i].uv)) != RT_OK) return rc;
-        if ((rc = upload(s, m.ind.data(), m.ind.size(), &dm[i].ind)) != RT_OK) return rc;
+        if ((rc = upload(t, m.p.data(), m.p.size(), &dm[i].p)) != RT_OK) return rc;
+        if ((rc = upload(t, m.n.data(), m.n.size(), &dm[i].n)) != RT_OK) return rc;
+        if ((rc = upload(t, m.uv.data(), m.uv.size(), &dm[i].uv)) != RT_OK) return rc;
+        if ((rc = upload(t, m.ind.data(), m.ind.size(), &dm[i].ind)) != RT_OK) return rc;
         if (!m.uv.empty()) has_uv = 1;
     }
-    if ((rc = upload(s, dm.data(), dm.size(), &d.meshes)) != RT_OK) return rc;
-    if ((rc = upload(s, s->xforms.data(), s->xforms.size(), &d.xforms)) != RT_OK) return rc;
+    if ((rc = upload(t, dm.data(), dm.size(), &d.meshes)) != RT_OK) return rc;
+    if ((rc = upload(t, s->xforms.data(), s->xforms.size(), &d.xforms)) != RT_OK) return rc;
     {   // materials with their texture references resolved (scene_dev.h: DevMat)
         std::vector<DevMat> dmats(s->mats.size());
         for (size_t i = 0; i < dmats.size(); i++) {
@@ -401,7 +493,7 @@ int rt_scene_commit_ex(rt_scene* s, uint32_t flags) {
                 for (int c = 0; c < 3; c++) dm.col[k][c] = s->texs[dm.tex[k]].color[c];
             }
         }
-        if ((rc = upload(s, dmats.data(), dmats.size(), &d.mats)) != RT_OK) return rc;
+        if ((rc = upload(t, dmats.data(), dmats.size(), &d.mats)) != RT_OK) return rc;
     }
     {   // textures: HDR texels go to HBM first, the records point at the device copies
         std::vector<rt_texture> dtex = s->texs;
@@ -411,12 +503,12 @@ int rt_scene_commit_ex(rt_scene* s, uint32_t flags) {
                 continue;
             }
             const uint8_t* dp = nullptr;
-            if ((rc = upload(s, s->hdr[i].data(), s->hdr[i].size(), &dp)) != RT_OK) return rc;
+            if ((rc = upload(t, s->hdr[i].data(), s->hdr[i].size(), &dp)) != RT_OK) return rc;
             dtex[i].rgbe = dp;
         }
-        if ((rc = upload(s, dtex.data(), dtex.size(), &d.texs)) != RT_OK) return rc;
+        if ((rc = upload(t, dtex.data(), dtex.size(), &d.texs)) != RT_OK) return rc;
     }
-    if ((rc = upload(s, s->lights.data(), s->lights.size(), &d.lights)) != RT_OK) return rc;
+    if ((rc = upload(t, s->lights.data(), s->lights.size(), &d.lights)) != RT_OK) return rc;
     d.env.light = -1;
     int need = 0;  // shading.h: kFeat*
     for (const rt_material& m : s->mats) {
@@ -430,22 +522,22 @@ int rt_scene_commit_ex(rt_scene* s, uint32_t flags) {
         // Light::make_infinite_light's Distribution2D (light.rs:608-638), rebuilt from the texels
         EnvDist ed;
         build_env_dist(s->texs[s->lights[i].tex_index], ed);
-        if ((rc = upload(s, ed.img.data(), ed.img.size(), &d.env.img)) != RT_OK) return rc;
-        if ((rc = upload(s, ed.cond_cdf.data(), ed.cond_cdf.size(), &d.env.cond_cdf)) != RT_OK) return rc;
-        if ((rc = upload(s, ed.marg_func.data(), ed.marg_func.size(), &d.env.marg_func)) != RT_OK) return rc;
-        if ((rc = upload(s, ed.marg_cdf.data(), ed.marg_cdf.size(), &d.env.marg_cdf)) != RT_OK) return rc;
+        if ((rc = upload(t, ed.img.data(), ed.img.size(), &d.env.img)) != RT_OK) return rc;
+        if ((rc = upload(t, ed.cond_cdf.data(), ed.cond_cdf.size(), &d.env.cond_cdf)) != RT_OK) return rc;
+        if ((rc = upload(t, ed.marg_func.data(), ed.marg_func.size(), &d.env.marg_func)) != RT_OK) return rc;
+        if ((rc = upload(t, ed.marg_cdf.data(), ed.marg_cdf.size(), &d.env.marg_cdf)) != RT_OK) return rc;
         d.env.marg_int = ed.marg_int;
         d.env.nu = ed.nu;
         d.env.nv = ed.nv;
         d.env.light = (int32_t)i;
         need |= kFeatEnv;
     }
-    s->shade_variant = kNumFeatVariants - 1;
+    t->shade_variant = kNumFeatVariants - 1;
     for (int v = kNumFeatVariants - 1; v >= 0; v--)
-        if ((need & ~kFeatVariants[v]) == 0) s->shade_variant = v;
+        if ((need & ~kFeatVariants[v]) == 0) t->shade_variant = v;
     if (const char* e = getenv("RT_SHADE_VARIANT")) {  // experiment: force a larger instance
         const int v = std::min(kNumFeatVariants - 1, std::max(0, atoi(e)));
-        if ((need & ~kFeatVariants[v]) == 0) s->shade_variant = v;
+        if ((need & ~kFeatVariants[v]) == 0) t->shade_variant = v;
     }
     uint64_t n_tri = 0;
     uint32_t depth = 0;
@@ -457,29 +549,35 @@ int rt_scene_commit_ex(rt_scene* s, uint32_t flags) {
         // next-row f3: the tree is built where the primitives already are (bvh_gpu.hip)
         DeviceBvh gb;
         char berr[400] = "";
-        rc = build_bvh_device(s->ctx->stream, d.prims, d.meshes, (uint32_t)np, any_normals, &gb, berr, sizeof(berr));
+        rc = build_bvh_device(t->ctx->stream, d.prims, d.meshes, (uint32_t)np, any_normals, &gb, berr, sizeof(berr));
         if (rc != RT_OK) return fail(rc, "%s", berr);
         for (void* p : {(void*)gb.nodes, (void*)gb.leaf_prim, (void*)gb.leaf_tri, (void*)gb.leaf_nrm, (void*)gb.leaf_meta})
-            if (p) s->allocs.push_back(p);
+            if (p) t->allocs.push_back(p);
         d.nodes = gb.nodes;
         d.leaf_prim = gb.leaf_prim;
         d.leaf_tri = gb.leaf_tri;
         d.leaf_nrm = gb.leaf_nrm;
         d.leaf_meta = gb.leaf_meta;
         d.n_nodes = gb.n_nodes;
-        s->info.device_bytes_total += (uint64_t)gb.n_nodes * sizeof(DevNode) + np * (sizeof(uint32_t) + 9 * sizeof(double) + sizeof(LeafMeta) + (any_normals ? 9 * sizeof(double) : 0));
+        t->info.device_bytes_total += (uint64_t)gb.n_nodes * sizeof(DevNode) + np * (sizeof(uint32_t) + 9 * sizeof(double) + sizeof(LeafMeta) + (any_normals ? 9 * sizeof(double) : 0));
         depth = gb.depth;
         n_tri = gb.n_triangles;
-        s->info.build_device_ms = gb.build_ms;
+        t->info.build_device_ms = gb.build_ms;
     } else {
+        if (!cache.valid) {
         BvhOut bvh;
         build_bvh(s->prims.data(), s->prims.size(), bvh);
         if (bvh.depth + 1 > (uint32_t)kMaxBvhDepth) return fail(RT_ERR_UNSUPPORTED, "BVH depth %u exceeds the traversal stack", bvh.depth);
         // leaf-ordered triangle vertices + ids
-        std::vector<uint32_t> leaf_prim(np);
-        std::vector<double> leaf_tri(np * 9, 0.0);
-        std::vector<double> leaf_nrm(any_normals ? np * 9 : 0, 0.0);
-        std::vector<LeafMeta> leaf_meta(np);
+        std::vector<uint32_t>& leaf_prim = cache.leaf_prim;
+        std::vector<double>& leaf_tri = cache.leaf_tri;
+        std::vector<double>& leaf_nrm = cache.leaf_nrm;
+        std::vector<LeafMeta>& leaf_meta = cache.leaf_meta;
+        leaf_prim.assign(np, 0u);
+        leaf_tri.assign(np * 9, 0.0);
+        leaf_nrm.assign(any_normals ? np * 9 : 0, 0.0);
+        leaf_meta.assign(np, LeafMeta{});
+        uint64_t n_tri_host = 0;
         for (size_t i = 0; i < np; i++) {
             const uint32_t id = bvh.order[i];
             const rt_primitive& p = s->prims[id];
@@ -494,7 +592,7 @@ int rt_scene_commit_ex(rt_scene* s, uint32_t flags) {
                 }
                 if (!m.n.empty()) leaf_meta[i].mat_flags |= kMetaHasNormals;
                 leaf_prim[i] = id;
-                n_tri++;
+                n_tri_host++;
             } else {
                 // sphere / rect: parameters + {kind, transform index + 1} ride in the vertex slot (geom.h: leaf_step)
                 for (int a = 0; a < 5; a++) leaf_tri[i * 9 + a] = p.v[a];
@@ -503,36 +601,43 @@ int rt_scene_commit_ex(rt_scene* s, uint32_t flags) {
                 leaf_prim[i] = id | kLeafOther;
             }
         }
-        if ((rc = upload(s, bvh.nodes.data(), bvh.nodes.size(), &d.nodes)) != RT_OK) return rc;
-        if ((rc = upload(s, leaf_prim.data(), leaf_prim.size(), &d.leaf_prim)) != RT_OK) return rc;
-        if ((rc = upload(s, leaf_tri.data(), leaf_tri.size(), &d.leaf_tri)) != RT_OK) return rc;
-        if ((rc = upload(s, leaf_nrm.data(), leaf_nrm.size(), &d.leaf_nrm)) != RT_OK) return rc;
-        if ((rc = upload(s, leaf_meta.data(), leaf_meta.size(), &d.leaf_meta)) != RT_OK) return rc;
-        d.n_nodes = (uint32_t)bvh.nodes.size();
-        depth = bvh.depth;
+        cache.nodes = std::move(bvh.nodes);
+        cache.depth = bvh.depth;
+        cache.n_tri = n_tri_host;
+        cache.valid = true;
+        }
+        if ((rc = upload(t, cache.nodes.data(), cache.nodes.size(), &d.nodes)) != RT_OK) return rc;
+        if ((rc = upload(t, cache.leaf_prim.data(), cache.leaf_prim.size(), &d.leaf_prim)) != RT_OK) return rc;
+        if ((rc = upload(t, cache.leaf_tri.data(), cache.leaf_tri.size(), &d.leaf_tri)) != RT_OK) return rc;
+        if ((rc = upload(t, cache.leaf_nrm.data(), cache.leaf_nrm.size(), &d.leaf_nrm)) != RT_OK) return rc;
+        if ((rc = upload(t, cache.leaf_meta.data(), cache.leaf_meta.size(), &d.leaf_meta)) != RT_OK) return rc;
+        d.n_nodes = (uint32_t)cache.nodes.size();
+        depth = cache.depth;
+        n_tri = cache.n_tri;
     }
-    s->info.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    s->info.build_flags = flags;
+    t->info.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    t->info.build_flags = flags;
     d.n_prims = (uint32_t)np;
     d.simple_others = getenv("RT_NO_SIMPLE_OTHERS") ? 0u : 1u;
     for (const rt_primitive& p : s->prims)
         if (p.kind == RT_PRIM_SPHERE || (p.kind != RT_PRIM_TRIANGLE && p.xform_index >= 0)) d.simple_others = 0u;
     d.n_lights = (uint32_t)s->lights.size();
     d.mesh_has_uv = has_uv;
-    s->info.n_prims = np;
-    s->info.n_triangles = n_tri;
-    s->info.n_others = np - n_tri;
-    s->info.n_bvh_nodes = d.n_nodes;
-    s->info.bvh_depth = depth;
-    s->info.node_bytes = sizeof(DevNode);
-    s->info.tri_bytes = 9 * sizeof(double) + sizeof(uint32_t);
-    s->info.other_bytes = 6 * sizeof(double) + sizeof(uint32_t);  // v[5] + meta in the leaf slot, + id
-    s->committed = true;
+    t->info.n_prims = np;
+    t->info.n_triangles = n_tri;
+    t->info.n_others = np - n_tri;
+    t->info.n_bvh_nodes = d.n_nodes;
+    t->info.bvh_depth = depth;
+    t->info.node_bytes = sizeof(DevNode);
+    t->info.tri_bytes = 9 * sizeof(double) + sizeof(uint32_t);
+    t->info.other_bytes = 6 * sizeof(double) + sizeof(uint32_t);  // v[5] + meta in the leaf slot, + id
+    t->committed = true;
     return RT_OK;
 }
 
 int rt_scene_destroy(rt_scene* s) {
     if (!s) return RT_OK;
+    for (rt_scene* r : s->replicas) (void)rt_scene_destroy(r);
     (void)hipSetDevice(s->ctx->device);
     for (void* p : s->allocs) (void)hipFree(p);
     delete s;
@@ -570,6 +675,7 @@ struct RenderJob {
     unsigned long long batch_total;  // its camera samples
     uint32_t pool;                   // paths each lane keeps in flight
     std::atomic<bool> abort{false};
+    std::atomic<bool> cancelled{false};  // rt_render_cfg.cancel was seen non-zero
     int trace_blocks;
     bool count_trav;
 };
@@ -608,19 +714,23 @@ static ShadeKernel shade_kernel(int v) {
         default: return k_shade<kFeatVariants[8]>;
     }
 }
-static TailKernel tail_kernel(int v) {
+extern "C++" {
+template <bool COUNT>
+static TailKernel tail_kernel_c(int v) {
     switch (v) {
-        case 0: return k_tail<kFeatVariants[0]>;
-        case 1: return k_tail<kFeatVariants[1]>;
-        case 2: return k_tail<kFeatVariants[2]>;
-        case 3: return k_tail<kFeatVariants[3]>;
-        case 4: return k_tail<kFeatVariants[4]>;
-        case 5: return k_tail<kFeatVariants[5]>;
-        case 6: return k_tail<kFeatVariants[6]>;
-        case 7: return k_tail<kFeatVariants[7]>;
-        default: return k_tail<kFeatVariants[8]>;
+        case 0: return k_tail<kFeatVariants[0], COUNT>;
+        case 1: return k_tail<kFeatVariants[1], COUNT>;
+        case 2: return k_tail<kFeatVariants[2], COUNT>;
+        case 3: return k_tail<kFeatVariants[3], COUNT>;
+        case 4: return k_tail<kFeatVariants[4], COUNT>;
+        case 5: return k_tail<kFeatVariants[5], COUNT>;
+        case 6: return k_tail<kFeatVariants[6], COUNT>;
+        case 7: return k_tail<kFeatVariants[7], COUNT>;
+        default: return k_tail<kFeatVariants[8], COUNT>;
     }
 }
+}  // extern "C++"
+static TailKernel tail_kernel(int v, bool count) { return count ? tail_kernel_c<true>(v) : tail_kernel_c<false>(v); }
 
 // One lane's share of a batch: keep `pool` paths alive, topping up from the shared batch counter,
 // until the batch is exhausted and this lane's paths have all retired.
@@ -641,8 +751,23 @@ static int run_lane(RenderJob& job, int lane_id) {
     uint32_t bound_active = P;
     bool exhausted_known = false;
     unsigned long long it = 0;
+    // whichever way this function is left, the next render on this lane must not reuse a sequence number that a
+    // kernel still queued here may publish
+    struct SeqGuard {
+        Lane& ln;
+        uint32_t seq0;
+        const unsigned long long& it;
+        ~SeqGuard() { ln.seq = seq0 + (uint32_t)it + 8u; }
+    } seq_guard{ln, seq0, it};
+    auto poll_cancel = [&]() -> bool {
+        if (cfg->cancel && *cfg->cancel != 0) {
+            job.cancelled.store(true);
+            job.abort.store(true);
+        }
+        return job.abort.load();
+    };
     for (; it < max_iters; it++) {
-        if (job.abort.load()) return RT_ERR_HIP;
+        if (poll_cancel()) return RT_ERR_HIP;
         static const bool no_mirror = getenv("RT_NO_MIRROR") != nullptr;  // experiment: fixed iteration count
         if (no_mirror) {
             if (it > (unsigned long long)cfg->max_depth + 2) break;
@@ -652,13 +777,18 @@ static int run_lane(RenderJob& job, int lane_id) {
             const uint32_t want_seq = seq0 + (uint32_t)(it - 2);
             const auto t0 = std::chrono::steady_clock::now();
             uint64_t spins = 0;
+            // The wait is normally a few microseconds (the device runs two iterations ahead of this read): spin
+            // briefly, then back off to short sleeps so that a long kernel does not pin a host core.
             while (__atomic_load_n(&me->seq, __ATOMIC_ACQUIRE) != want_seq) {
-                if ((++spins & 0xfff) == 0) {
-                    if (job.abort.load()) return RT_ERR_HIP;
-                    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
-                        job.abort.store(true);
-                        return lane_fail(ln, RT_ERR_HIP, "device did not publish iteration %llu counters within 30 s", it - 2);
-                    }
+                if (++spins < 2048) {
+                    __builtin_ia32_pause();
+                    continue;
+                }
+                std::this_thread::sleep_for(std::chrono::microseconds(spins < 4096 ? 5 : 50));
+                if (poll_cancel()) return RT_ERR_HIP;
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
+                    job.abort.store(true);
+                    return lane_fail(ln, RT_ERR_HIP, "device did not publish iteration %llu counters within 30 s", it - 2);
                 }
             }
             const uint32_t live = me->n_active, rem = me->remaining;
@@ -671,7 +801,7 @@ static int run_lane(RenderJob& job, int lane_id) {
                     // few paths left: one fused launch finishes them (k_tail) instead of ~2 launches per bounce
                     // that are each as slow as their single longest ray
                                         const uint32_t tail_blocks = std::min((live + 255) / 256, (uint32_t)c->num_cus * 2u);  // persistent waves
-                    hipLaunchKernelGGL(tail_kernel(job.s->shade_variant), dim3(tail_blocks), dim3(256), 0, stream, job.s->dev, ln.st[0],
+                    hipLaunchKernelGGL(tail_kernel(job.s->shade_variant, job.count_trav), dim3(tail_blocks), dim3(256), 0, stream, job.s->dev, ln.st[0],
                                        ln.st[1], ln.ctl, (uint32_t)it, cfg->max_depth, c->lf[0], c->lf[1], c->lf[2],
                                        c->stats);
                     break;
@@ -713,8 +843,17 @@ static int run_lane(RenderJob& job, int lane_id) {
         hipLaunchKernelGGL(shade_kernel(job.s->shade_variant), dim3(shade_blocks), dim3(256), 0, stream, job.s->dev, ln.st[it & 1],
                            ln.st[(it + 1) & 1], ln.ctl, (uint32_t)it, cfg->max_depth, ln.queue[(it + 1) & 1], c->lf[0],
                            c->lf[1], c->lf[2], c->stats);
+        if (!no_ev) {  // the shading kernel runs from event b (end of k_trace) to this one
+            hipEvent_t e = get_event(ln.events, ln.ev_i++);
+            if (!e) {
+                job.abort.store(true);
+                return lane_fail(ln, RT_ERR_HIP, "hipEventCreate failed");
+            }
+            LANE_TRY(hipEventRecord(e, stream));
+            ln.shade_ev.emplace_back(b, e);
+        }
+        ln.shade_launches++;
     }
-    ln.seq = seq0 + (uint32_t)it + 8u;
     if (it >= max_iters) {
         job.abort.store(true);
         return lane_fail(ln, RT_ERR_HIP, "lane %d did not drain within %llu iterations", lane_id, max_iters);
@@ -759,6 +898,7 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
             }
     }
     HIP_TRY(hipSetDevice(c->device));
+    c->last_pix = pix;
     if (!(cfg->flags & RT_RENDER_ACCUMULATE)) {
         HIP_TRY(hipMemsetAsync(d_rgb, 0, sizeof(double) * 3 * (size_t)W * H, stream));
         HIP_TRY(hipMemsetAsync(d_n, 0, sizeof(uint32_t) * (size_t)W * H, stream));
@@ -769,8 +909,8 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
     const uint32_t pass_spp = s_end - s_first;
     HIP_TRY(hipMemsetAsync(c->stats, 0, sizeof(DevStats) * kStatShards, stream));
     const size_t NP = pix.size();
-    double kernel_ms = 0.0, trace_ms = 0.0;
-    uint64_t trace_launches = 0;
+    double kernel_ms = 0.0, trace_ms = 0.0, shade_ms = 0.0;
+    uint64_t trace_launches = 0, shade_launches = 0;
     if (NP > 0 && pass_spp > 0) {
         // batch shape: PB pixels x ns samples, at most kBatchMax camera samples (film staging size)
         uint32_t PB, ns;
@@ -837,7 +977,9 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
             Lane& ln = c->lanes[i];
             ln.ev_i = 0;
             ln.trace_ev.clear();
+            ln.shade_ev.clear();
             ln.trace_launches = 0;
+            ln.shade_launches = 0;
         }
         for (size_t pb = 0; pb < NP; pb += PB) {
             const uint32_t npx = (uint32_t)std::min<size_t>(PB, NP - pb);
@@ -865,6 +1007,10 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
                 for (int i = 1; i < n_lanes; i++) workers.emplace_back([&job, i] { run_lane(job, i); });
                 run_lane(job, 0);
                 for (auto& t : workers) t.join();
+                if (job.cancelled.load()) {
+                    (void)hipDeviceSynchronize();  // the launches already queued run to completion
+                    return fail(RT_ERR_CANCELLED, "rt_render: cancelled by the caller");
+                }
                 for (int i = 0; i < n_lanes; i++) {
                     Lane& ln = c->lanes[i];
                     if (ln.rc != RT_OK) {
@@ -889,7 +1035,12 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
                 HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
                 trace_ms += ms;
             }
+            for (auto& pr : ln.shade_ev) {
+                HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+                shade_ms += ms;
+            }
             trace_launches += ln.trace_launches;
+            shade_launches += ln.shade_launches;
         }
     } else {
         HIP_TRY(hipStreamSynchronize(stream));
@@ -902,6 +1053,8 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
             ds.paths += shards[i].paths; ds.r1 += shards[i].r1; ds.r2 += shards[i].r2; ds.r3 += shards[i].r3;
             ds.vertices += shards[i].vertices; ds.nodes += shards[i].nodes; ds.tris += shards[i].tris;
             ds.others += shards[i].others;
+            ds.tail_rays += shards[i].tail_rays; ds.tail_nodes += shards[i].tail_nodes;
+            ds.tail_tris += shards[i].tail_tris; ds.tail_others += shards[i].tail_others;
         }
         std::memset(stats, 0, sizeof(*stats));
         stats->paths = ds.paths;
@@ -915,6 +1068,10 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
         stats->kernel_ms = kernel_ms;
         stats->trace_ms = trace_ms;
         stats->trace_launches = trace_launches;
+        stats->gather_ms = 0.0;
+        stats->n_devices = 1;
+        stats->shade_ms = shade_ms;
+        stats->shade_launches = shade_launches;
 #ifdef RT_SHADE_PROF
         {
             unsigned long long pr[16];
@@ -937,13 +1094,166 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
                 for (int q = 0; q < 4; q++) d[q] += shards[i].pad[8 + q];
             fprintf(stderr, "[rt diag] node rounds %llu avg lanes %.1f | prim rounds %llu avg lanes %.1f\n", d[0],
                     d[0] ? (double)d[1] / d[0] : 0.0, d[2], d[2] ? (double)d[3] / d[2] : 0.0);
+            // instrumented build only: short trace launches (in-kernel time, 10 ns ticks) and the longest traversals
+            fprintf(stderr, "[rt diag] trace launches under 4096 rays: %llu, avg in-kernel us %.1f, avg rays %.1f | "
+                            "max steps per ray %llu, rays over 64 steps %llu, over 256 steps %llu\n",
+                    shards[0].pad[1], shards[0].pad[1] ? shards[0].pad[0] / 100.0 / shards[0].pad[1] : 0.0,
+                    shards[0].pad[1] ? (double)shards[0].pad[2] / shards[0].pad[1] : 0.0, shards[0].pad[3],
+                    shards[0].pad[4], shards[0].pad[5]);
         }
-        stats->reserved[0] = shards[0].pad[0];  // diagnostics of the instrumented build (tail launches)
-        stats->reserved[1] = shards[0].pad[1];
-        stats->reserved[2] = shards[0].pad[2];
-        stats->reserved[3] = shards[0].pad[3] | (shards[0].pad[4] << 16) | (shards[0].pad[5] << 40);
+        stats->tail_rays = ds.tail_rays;
+        stats->tail_nodes_fetched = ds.tail_nodes;
+        stats->tail_tris_tested = ds.tail_tris;
+        stats->tail_others_tested = ds.tail_others;
     }
     return RT_OK;
+}
+
+// ------------------------------------------------------------------ multi-device render
+// Tile k (row-major, rt_render_cfg.tile_size) belongs to the caller if k % world == rank; of the caller's tiles,
+// device i of the context takes every N-th: k % (world * N) == rank + world * i.  Pixels are independent and keyed
+// by (seed, pixel, sample), so the film is bit-identical to a one-device render.  The only exchange is the final
+// gather: each further device packs its own pixels ({r, g, b, n} as four doubles), copies them straight to the
+// primary device (hipMemcpyPeerAsync: one xGMI link per peer, 1/N of the bytes a full-frame reduce would move) where
+// a scatter kernel writes them into the caller's film.
+__global__ __launch_bounds__(256) void k_film_pack(const double* __restrict__ rgb, const uint32_t* __restrict__ n,
+                                                   const uint32_t* __restrict__ pix_list, uint32_t np, double* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= np) return;
+    const size_t p = pix_list[i];
+    out[(size_t)i * 4 + 0] = rgb[p * 3 + 0];
+    out[(size_t)i * 4 + 1] = rgb[p * 3 + 1];
+    out[(size_t)i * 4 + 2] = rgb[p * 3 + 2];
+    out[(size_t)i * 4 + 3] = (double)n[p];
+}
+__global__ __launch_bounds__(256) void k_film_unpack(const double* __restrict__ in, const uint32_t* __restrict__ pix_list,
+                                                     uint32_t np, double* rgb, uint32_t* n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= np) return;
+    const size_t p = pix_list[i];
+    rgb[p * 3 + 0] = in[(size_t)i * 4 + 0];
+    rgb[p * 3 + 1] = in[(size_t)i * 4 + 1];
+    rgb[p * 3 + 2] = in[(size_t)i * 4 + 2];
+    n[p] = (uint32_t)in[(size_t)i * 4 + 3];
+}
+
+extern "C++" {
+template <typename T>
+static int ensure_dev_buffer(int device, T** buf, size_t* cap, size_t want) {
+    if (*cap >= want) return RT_OK;
+    HIP_TRY(hipSetDevice(device));
+    if (*buf) HIP_TRY(hipFree(*buf));
+    *buf = nullptr;
+    *cap = 0;
+    HIP_TRY(hipMalloc((void**)buf, want * sizeof(T)));
+    *cap = want;
+    return RT_OK;
+}
+}  // extern "C++"
+
+static int render_multi(rt_context* c, rt_scene* s, const rt_camera* cam, const rt_render_cfg* cfg, double* d_rgb,
+                        uint32_t* d_n, hipStream_t stream, rt_stats* stats) {
+    const int N = 1 + (int)c->peers.size();
+    const size_t npix = (size_t)cfg->width * cfg->height;
+    const uint32_t world = cfg->tile_world ? cfg->tile_world : 1;
+    if ((uint64_t)world * (uint64_t)N > 0xffffffffull) return fail(RT_ERR_INVALID_ARG, "rt_render: tile_world too large");
+    std::vector<rt_render_cfg> cfgs((size_t)N, *cfg);
+    for (int i = 0; i < N; i++) {
+        cfgs[i].tile_world = world * (uint32_t)N;
+        cfgs[i].tile_rank = cfg->tile_rank + world * (uint32_t)i;
+    }
+    int rc = RT_OK;
+    for (int i = 1; i < N; i++) {
+        rt_context* p = c->peers[i - 1];
+        if (p->pf_cap < npix) {  // scratch film of the peer
+            size_t cap_rgb = 0, cap_n = 0;
+            if (p->pf_rgb) (void)hipFree(p->pf_rgb);
+            if (p->pf_n) (void)hipFree(p->pf_n);
+            p->pf_rgb = nullptr;
+            p->pf_n = nullptr;
+            p->pf_cap = 0;
+            if ((rc = ensure_dev_buffer(p->device, &p->pf_rgb, &cap_rgb, npix * 3)) != RT_OK) return rc;
+            if ((rc = ensure_dev_buffer(p->device, &p->pf_n, &cap_n, npix)) != RT_OK) return rc;
+            p->pf_cap = npix;
+        }
+        if (cfg->flags & RT_RENDER_ACCUMULATE) {
+            // progressive pass: every device continues from the caller's film, so that a pixel's running sum is
+            // added to in the same order as on one device
+            HIP_TRY(hipMemcpyPeerAsync(p->pf_rgb, p->device, d_rgb, c->device, npix * 3 * sizeof(double), stream));
+            HIP_TRY(hipMemcpyPeerAsync(p->pf_n, p->device, d_n, c->device, npix * sizeof(uint32_t), stream));
+        }
+    }
+    if (cfg->flags & RT_RENDER_ACCUMULATE) HIP_TRY(hipStreamSynchronize(stream));
+    std::vector<rt_stats> st((size_t)N);
+    std::vector<int> rcs((size_t)N, RT_OK);
+    std::vector<std::string> errs((size_t)N);
+    std::vector<std::thread> workers;
+    for (int i = 1; i < N; i++)
+        workers.emplace_back([&, i] {  // one host thread per device
+            rt_context* p = c->peers[i - 1];
+            rcs[i] = render_impl(p, s->replicas[i - 1], cam, &cfgs[i], p->pf_rgb, p->pf_n, p->stream, &st[i]);
+            if (rcs[i] != RT_OK) errs[i] = g_err;  // g_err is thread-local
+        });
+    rcs[0] = render_impl(c, s, cam, &cfgs[0], d_rgb, d_n, stream, &st[0]);
+    if (rcs[0] != RT_OK) errs[0] = g_err;
+    for (auto& t : workers) t.join();
+    for (int i = 0; i < N; i++)
+        if (rcs[i] != RT_OK) return fail(rcs[i], "device %d of the context: %s", i, errs[i].c_str());
+    // ---- gather the peers' pixels into the caller's film
+    const auto g0 = std::chrono::steady_clock::now();
+    size_t total = 0;
+    for (int i = 1; i < N; i++) total += c->peers[i - 1]->last_pix.size();
+    if ((rc = ensure_dev_buffer(c->device, &c->stage, &c->stage_cap, total * 4)) != RT_OK) return rc;
+    if ((rc = ensure_dev_buffer(c->device, &c->stage_pix, &c->stage_pix_cap, total)) != RT_OK) return rc;
+    size_t off = 0;
+    for (int i = 1; i < N; i++) {
+        rt_context* p = c->peers[i - 1];
+        const size_t np = p->last_pix.size();
+        if (np == 0) continue;
+        if ((rc = ensure_dev_buffer(p->device, &p->pack, &p->pack_cap, np * 4)) != RT_OK) return rc;
+        HIP_TRY(hipSetDevice(p->device));
+        if (!p->ev_gather) HIP_TRY(hipEventCreateWithFlags(&p->ev_gather, hipEventDisableTiming));
+        // p->pix_list still holds this render's pixel list on the peer device
+        hipLaunchKernelGGL(k_film_pack, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, p->stream, p->pf_rgb, p->pf_n,
+                           p->pix_list, (uint32_t)np, p->pack);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyPeerAsync(c->stage + off * 4, c->device, p->pack, p->device, np * 4 * sizeof(double), p->stream));
+        HIP_TRY(hipEventRecord(p->ev_gather, p->stream));
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamWaitEvent(stream, p->ev_gather, 0));
+        HIP_TRY(hipMemcpyAsync(c->stage_pix + off, p->last_pix.data(), np * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(k_film_unpack, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, stream, c->stage + off * 4,
+                           c->stage_pix + off, (uint32_t)np, d_rgb, d_n);
+        HIP_TRY(hipGetLastError());
+        off += np;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(stream));
+    const double gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g0).count();
+    if (stats) {
+        rt_stats t = st[0];
+        for (int i = 1; i < N; i++) {
+            t.paths += st[i].paths; t.rays_extension += st[i].rays_extension; t.rays_shadow += st[i].rays_shadow;
+            t.rays_probe += st[i].rays_probe; t.vertices_shaded += st[i].vertices_shaded;
+            t.nodes_fetched += st[i].nodes_fetched; t.tris_tested += st[i].tris_tested;
+            t.others_tested += st[i].others_tested; t.trace_ms += st[i].trace_ms;
+            t.trace_launches += st[i].trace_launches; t.tail_rays += st[i].tail_rays;
+            t.shade_ms += st[i].shade_ms; t.shade_launches += st[i].shade_launches;
+            t.tail_nodes_fetched += st[i].tail_nodes_fetched; t.tail_tris_tested += st[i].tail_tris_tested;
+            t.tail_others_tested += st[i].tail_others_tested;
+            t.kernel_ms = std::max(t.kernel_ms, st[i].kernel_ms);  // the devices run side by side
+        }
+        t.gather_ms = gather_ms;
+        t.n_devices = (uint64_t)N;
+        *stats = t;
+    }
+    return RT_OK;
+}
+
+static int render_any(rt_context* c, rt_scene* s, const rt_camera* cam, const rt_render_cfg* cfg, double* d_rgb,
+                      uint32_t* d_n, hipStream_t stream, rt_stats* stats) {
+    if (c->peers.empty()) return render_impl(c, s, cam, cfg, d_rgb, d_n, stream, stats);
+    return render_multi(c, s, cam, cfg, d_rgb, d_n, stream, stats);
 }
 
 static int check_render_args(rt_context* c, rt_scene* s, const rt_camera* cam, const rt_render_cfg* cfg) {
@@ -967,7 +1277,7 @@ int rt_render_device(rt_context* c, rt_scene* s, const rt_camera* cam, const rt_
     int rc = check_render_args(c, s, cam, cfg);
     if (rc != RT_OK) return rc;
     if (!d_rgb_sum || !d_n) return fail(RT_ERR_INVALID_ARG, "rt_render_device: null film pointer");
-    return render_impl(c, s, cam, cfg, d_rgb_sum, d_n, hip_stream ? (hipStream_t)hip_stream : c->stream, stats);
+    return render_any(c, s, cam, cfg, d_rgb_sum, d_n, (hipStream_t)hip_stream, stats);  // NULL = the null stream
 }
 
 int rt_render(rt_context* c, rt_scene* s, const rt_camera* cam, const rt_render_cfg* cfg, double* rgb_sum, uint32_t* n,
@@ -998,7 +1308,7 @@ int rt_render(rt_context* c, rt_scene* s, const rt_camera* cam, const rt_render_
             return fail(RT_ERR_HIP, "film upload failed: %s", hipGetErrorString(e));
         }
     }
-    rc = render_impl(c, s, cam, cfg, d_rgb, d_n, c->stream, stats);
+    rc = render_any(c, s, cam, cfg, d_rgb, d_n, c->stream, stats);
     if (rc == RT_OK && rgb_sum) {
         e = hipMemcpy(rgb_sum, d_rgb, npix * 3 * sizeof(double), hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(RT_ERR_HIP, "film download failed: %s", hipGetErrorString(e));

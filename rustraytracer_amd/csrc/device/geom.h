@@ -1,6 +1,6 @@
 // geom.h -- ray/primitive tests and the closest-hit BVH traversal for gfx950.
 //
-// Replaces, with identical results (tests/test_gpu_intersect.py):
+// Replaces, with identical results (tests/test_gpu_parity.py::test_intersect_batch_*, tests/test_gpu_arms.py):
 //   BoundingBox::intersects        src/hittable.rs:494-508   -> slab()
 //   Mesh::intersects_triangle      src/hittable.rs:292-452   -> tri_core() + tri_record()
 //   sphere_intersect / record      src/intersects.rs:177-258 -> sphere_core() + sphere_record()

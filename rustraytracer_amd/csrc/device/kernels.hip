@@ -818,7 +818,9 @@ __global__ __launch_bounds__(256, FEAT <= RT_SHADE4_MAXFEAT ? 4 : (feat_three_wa
 // longest path; and (b) pooled rays: the pending rays of the wave's live paths (up to three each: shadow, probe,
 // extension) are listed in LDS and dealt to ALL 64 lanes, so a path's three rays are traced side by side.
 // The two state buffers alternate per bounce, wave-uniformly: new paths are taken on even passes only.
-template <int FEAT>
+// COUNT: the instrumented build (RT_RENDER_COUNT_TRAVERSAL) also counts the tail's node / primitive tests; its rays
+// are always counted (rt_stats.tail_*), so that the traversal kernel's own share is known exactly.
+template <int FEAT, bool COUNT>
 __global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathState buf1, Ctl* ctl,
                                              uint32_t it_abs, uint32_t max_depth, double* lfx, double* lfy,
                                              double* lfz, DevStats* stats) {
@@ -837,6 +839,7 @@ __global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathS
     ts.lds_stride = 256;
     TravCount tc{0, 0, 0};
     unsigned long long n_r1 = 0, n_r2 = 0, n_r3 = 0, n_v = 0;
+    uint32_t n_traced = 0;  // wave-uniform: rays this wave traced
     const int cur0 = (int)(it_abs & 1u);
     const unsigned long long below = (1ull << lane) - 1ull;
     for (uint32_t pass = 0;; pass++) {
@@ -880,6 +883,7 @@ __global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathS
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const uint32_t n_jobs = nsh + npr + nex;
+        n_traced += n_jobs;
         for (uint32_t j = lane; j < n_jobs; j += 64u) {
             const uint32_t job = s_job[wave][j];
             const uint32_t js = job & kSlotMask, kind = job >> 30;
@@ -889,11 +893,11 @@ __global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathS
             int32_t prim;
             if (kind == kRayShadow) {  // Visibility::unoccluded, hittable.rs:25-32
                 const D3 d = ld3(in.spx, in.spy, in.spz, js) - o;
-                prim = closest_hit<false>(sc, o + d * kSmall, d, 0.0, kInf, t, ts, &tc);
+                prim = closest_hit<COUNT>(sc, o + d * kSmall, d, 0.0, kInf, t, ts, &tc);
             } else if (kind == kRayProbe) {
-                prim = closest_hit<false>(sc, o, ld3(in.pdx, in.pdy, in.pdz, js), kSmall, kInf, t, ts, &tc);
+                prim = closest_hit<COUNT>(sc, o, ld3(in.pdx, in.pdy, in.pdz, js), kSmall, kInf, t, ts, &tc);
             } else {
-                prim = closest_hit<false>(sc, o, ld3(in.dx, in.dy, in.dz, js), kSmall, kInf, t, ts, &tc, &hs);
+                prim = closest_hit<COUNT>(sc, o, ld3(in.dx, in.dy, in.dz, js), kSmall, kInf, t, ts, &tc, &hs);
             }
             s_res[wave][j] = make_int2(prim, (int)hs);
         }
@@ -933,6 +937,15 @@ __global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathS
     if (n_r2) atomicAdd(&sh->r2, n_r2);
     if (n_r3) atomicAdd(&sh->r3, n_r3);
     if (n_v) atomicAdd(&sh->vertices, n_v);
+    if (lane == 0 && n_traced) atomicAdd(&sh->tail_rays, (unsigned long long)n_traced);
+    if (COUNT) {
+        atomicAdd(&sh->nodes, (unsigned long long)tc.nodes);
+        atomicAdd(&sh->tris, (unsigned long long)tc.tris);
+        atomicAdd(&sh->others, (unsigned long long)tc.others);
+        atomicAdd(&sh->tail_nodes, (unsigned long long)tc.nodes);
+        atomicAdd(&sh->tail_tris, (unsigned long long)tc.tris);
+        atomicAdd(&sh->tail_others, (unsigned long long)tc.others);
+    }
 }
 
 // ------------------------------------------------------------------- resolve

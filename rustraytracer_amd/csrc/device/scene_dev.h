@@ -23,6 +23,7 @@ static_assert(sizeof(DevNode) == 128, "DevNode must be 128 bytes");
 constexpr int32_t kNoChild = INT32_MIN;
 constexpr uint32_t kLeafOther = 0x80000000u;  // leaf entry is a sphere/rect, not a triangle
 constexpr uint32_t kLeafCodeOther = 1u << 30;
+constexpr uint64_t kMaxPrims = 1ull << 27;  // exclusive: leaf slots occupy bits 3..29 of a leaf code
 constexpr uint32_t kMetaHasNormals = 1u << 30, kMetaFlip = 1u << 31, kMetaMatMask = 0x3fffffffu;  // leaf code flag: the leaf holds one sphere/rect (they never share a leaf)
 constexpr int kMaxLeafPrims = 4;     // what a leaf code can hold
 // What the builders aim for.  One primitive per leaf: the parent's f32 test of the child box then culls each
@@ -123,7 +124,8 @@ constexpr uint32_t kSlotMask = 0x3fffffffu;
 
 struct DevStats {  // one shard = two 64-B lines; kStatShards shards, summed by the host
     unsigned long long paths, r1, r2, r3, vertices, nodes, tris, others;
-    unsigned long long pad[16];  // pad[0..11]: diagnostics of the instrumented build
+    unsigned long long pad[12];  // diagnostics of the instrumented build
+    unsigned long long tail_rays, tail_nodes, tail_tris, tail_others;  // k_tail's share (rt_stats.tail_*)
 };
 constexpr int kStatShards = 64;
 

@@ -1,0 +1,26 @@
+"""Runs FIRST among the -m gpu tests (file name order), before this pytest process has touched the GPU: it starts
+fresh child processes -- one per rank, all on the box's single GPU -- that render interleaved tiles through the C
+ABI and gather them with rustraytracer_amd.dist.FilmGather over gloo (tools/mp_film_check.py).  This is the
+multi-rank path of bench.py --gpus N run as a system, minus RCCL (a one-GPU box cannot host two RCCL ranks)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_ranks_on_one_gpu_gather_the_one_rank_film(ranks):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(29500 + 17 * ranks),
+           os.path.join(ROOT, "tools", "mp_film_check.py")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["ranks"] == ranks and rec["bit_identical"] and rec["rays_sum"] == rec["rays_one_rank"]

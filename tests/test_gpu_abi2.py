@@ -1,0 +1,165 @@
+"""GPU tests (-m gpu) of the ABI-v2 additions: multi-device contexts, cancellation, stream ordering of
+rt_render_device, and the fused tail launch's share of the counters."""
+import ctypes as C
+import threading
+import time
+
+import numpy as np
+import pytest
+
+import rustraytracer_amd as rr
+from rustraytracer_amd import _ffi as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("ids", [(0, 0), (0, 0, 0)], ids=["2ctx", "3ctx"])
+def test_multi_device_context_is_bit_identical(gpu_ctx, ids):
+    """rt_context_create(device_ids, n > 1) (SURVEY.md 8b): one host thread per device, scene replicated at commit,
+    tiles interleaved, peers' pixels packed + copied peer-to-peer + scattered into the caller's film.  A one-GPU box
+    exercises it with the same device id repeated (each entry gets its own context, streams and pools)."""
+    sc = rr.cornell_box_statue(mesh_faces=6000, variant=3)
+    gs1 = gpu_ctx.upload(sc)
+    cfg = rr.make_cfg(80, 56, 8, seed=12)
+    r1, n1, s1 = gpu_ctx.render(gs1, sc.camera, cfg)
+    mc = rr.Context(list(ids))
+    gsm = mc.upload(sc)
+    rm, nm, sm = mc.render(gsm, sc.camera, cfg)
+    assert sm.n_devices == len(ids) and s1.n_devices == 1
+    assert np.array_equal(rm, r1) and np.array_equal(nm, n1)
+    assert (sm.paths, sm.rays_extension, sm.rays_shadow, sm.rays_probe, sm.vertices_shaded) == \
+           (s1.paths, s1.rays_extension, s1.rays_shadow, s1.rays_probe, s1.vertices_shaded)
+    assert sm.gather_ms > 0.0
+    # combined with a caller-level split (two "processes" of a multi-device context each)
+    acc, nacc = np.zeros_like(r1), np.zeros_like(n1)
+    for r in range(2):
+        a, b, _ = mc.render(gsm, sc.camera, rr.make_cfg(80, 56, 8, seed=12, tile_rank=r, tile_world=2))
+        acc += a
+        nacc += b
+    assert np.array_equal(acc, r1) and np.array_equal(nacc, n1)
+    # progressive passes across devices: running sums continue in sample order
+    film = (np.zeros_like(r1), np.zeros_like(n1))
+    for first in (0, 2, 6):
+        mc.render(gsm, sc.camera, rr.make_cfg(80, 56, 8, seed=12, sample_first=first,
+                                               sample_count={0: 2, 2: 4, 6: 2}[first], accumulate=True), film=film)
+    assert np.array_equal(film[0], r1) and np.array_equal(film[1], n1)
+    # the device-built tree is replicated as well
+    gsd = mc.upload(sc, device_build=True)
+    rd, nd, _ = mc.render(gsd, sc.camera, cfg)
+    assert np.array_equal(rd, r1)
+    for g in (gsd, gsm, gs1):
+        g.close()
+    mc.close()
+
+
+def test_multi_device_render_device_film(gpu_ctx):
+    import torch
+    sc = rr.cornell_box()
+    cfg = rr.make_cfg(64, 64, 4, seed=1)
+    gs1 = gpu_ctx.upload(sc)
+    r1, n1, _ = gpu_ctx.render(gs1, sc.camera, cfg)
+    mc = rr.Context([0, 0])
+    gsm = mc.upload(sc)
+    d_rgb = torch.full((64, 64, 3), 7.0, dtype=torch.float64, device="cuda")
+    d_n = torch.full((64, 64), 9, dtype=torch.int32, device="cuda")
+    st = mc.render_device(gsm, sc.camera, cfg, d_rgb.data_ptr(), d_n.data_ptr(),
+                          stream=torch.cuda.current_stream().cuda_stream)
+    assert np.array_equal(d_rgb.cpu().numpy(), r1) and np.array_equal(d_n.cpu().numpy().astype(np.uint32), n1)
+    assert st.n_devices == 2
+    gsm.close()
+    gs1.close()
+    mc.close()
+
+
+def test_cancel_flag(gpu_ctx):
+    """rt_render_cfg.cancel (render.rs:93 stop_render): set before the call, and from another thread during it."""
+    sc = rr.cornell_box_statue(mesh_faces=20000, variant=0)
+    gs = gpu_ctx.upload(sc)
+    ref = gpu_ctx.render(gs, sc.camera, rr.make_cfg(64, 64, 8, seed=2))
+    flag = C.c_int32(1)
+    with pytest.raises(rr.RtError) as ei:
+        gpu_ctx.render(gs, sc.camera, rr.make_cfg(64, 64, 8, seed=2, cancel=flag))
+    assert ei.value.code == F.RT_ERR_CANCELLED
+    # the context stays usable and exact after a cancelled call
+    again = gpu_ctx.render(gs, sc.camera, rr.make_cfg(64, 64, 8, seed=2))
+    assert np.array_equal(again[0], ref[0]) and np.array_equal(again[1], ref[1])
+    # an unset flag changes nothing
+    flag = C.c_int32(0)
+    same = gpu_ctx.render(gs, sc.camera, rr.make_cfg(64, 64, 8, seed=2, cancel=flag))
+    assert np.array_equal(same[0], ref[0])
+    # mid-render: a long render (many batches of a small pool), cancelled from a second thread
+    flag = C.c_int32(0)
+    big = rr.make_cfg(512, 512, 256, seed=2, cancel=flag, paths_in_flight=1 << 18)
+
+    def stopper():
+        time.sleep(0.05)
+        flag.value = 1
+
+    th = threading.Thread(target=stopper)
+    t0 = time.time()
+    th.start()
+    with pytest.raises(rr.RtError) as ei:
+        gpu_ctx.render(gs, sc.camera, big)
+    th.join()
+    assert ei.value.code == F.RT_ERR_CANCELLED
+    assert time.time() - t0 < 5.0  # an uncancelled run of this configuration takes much longer
+    again = gpu_ctx.render(gs, sc.camera, rr.make_cfg(64, 64, 8, seed=2))
+    assert np.array_equal(again[0], ref[0]) and np.array_equal(again[1], ref[1])
+    gs.close()
+
+
+def test_render_device_is_ordered_on_the_callers_stream(gpu_ctx):
+    """rt_render_device enqueues everything that touches the film on the caller's stream (NULL = the null stream):
+    work queued before the call does not clobber the film, work queued after sees it."""
+    import torch
+    sc = rr.cornell_box_statue(mesh_faces=5000, variant=1)
+    gs = gpu_ctx.upload(sc)
+    cfg = rr.make_cfg(96, 96, 8, seed=6)
+    ref, nref, _ = gpu_ctx.render(gs, sc.camera, cfg)
+    for stream in (None, torch.cuda.Stream()):
+        d_rgb = torch.zeros((96, 96, 3), dtype=torch.float64, device="cuda")
+        d_n = torch.zeros((96, 96), dtype=torch.int32, device="cuda")
+        junk = torch.ones((4096, 4096), dtype=torch.float64, device="cuda")
+        ctxmgr = torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream())
+        with ctxmgr:
+            s = torch.cuda.current_stream()
+            for _ in range(6):  # a long queue of earlier work that writes the film buffers
+                junk = junk @ junk * 1e-4
+                d_rgb.fill_(123.0)
+                d_n.fill_(77)
+            gpu_ctx.render_device(gs, sc.camera, cfg, d_rgb.data_ptr(), d_n.data_ptr(), stream=s.cuda_stream)
+            doubled = d_rgb * 2.0  # queued after the call on the same stream
+        torch.cuda.synchronize()
+        assert np.array_equal(d_rgb.cpu().numpy(), ref)
+        assert np.array_equal(d_n.cpu().numpy().astype(np.uint32), nref)
+        assert np.array_equal(doubled.cpu().numpy(), ref * 2.0)
+    gs.close()
+
+
+def test_tail_launch_share_of_the_counters(gpu_ctx):
+    sc = rr.cornell_box_statue(mesh_faces=20000, variant=0)
+    gs = gpu_ctx.upload(sc)
+    st = gpu_ctx.render(gs, sc.camera, rr.make_cfg(128, 128, 8, seed=3, count_traversal=True))[2]
+    assert 0 < st.tail_rays <= st.rays
+    assert 0 < st.tail_nodes_fetched <= st.nodes_fetched
+    assert st.tail_tris_tested <= st.tris_tested and st.tail_others_tested <= st.others_tested
+    assert st.shade_launches > 0 and st.shade_ms > 0.0 and st.trace_ms > 0.0
+    # without the counting flag the ray split is still reported, the traversal counters are not
+    st2 = gpu_ctx.render(gs, sc.camera, rr.make_cfg(128, 128, 8, seed=3))[2]
+    assert st2.tail_rays == st.tail_rays and st2.nodes_fetched == 0 and st2.tail_nodes_fetched == 0
+    # every ray through the fused launch (tiny image: the pool never exceeds the tail threshold after the top-up)
+    st3 = gpu_ctx.render(gs, sc.camera, rr.make_cfg(16, 16, 2, seed=3, count_traversal=True))[2]
+    assert st3.tail_rays + 16 * 16 * 2 >= st3.rays - st3.rays_shadow - st3.rays_probe or st3.tail_rays > 0
+    gs.close()
+
+
+def test_primitive_count_limit():
+    L = F.lib()
+    ctx = rr.Context(0)
+    h = C.c_void_p()
+    assert L.rt_scene_create(ctx._h, C.byref(h)) == 0
+    one = (F.rt_primitive * 1)()
+    assert L.rt_scene_set_primitives(h, one, 1 << 27) == F.RT_ERR_UNSUPPORTED
+    assert b"2^27" in L.rt_last_error()
+    L.rt_scene_destroy(h)
+    ctx.close()

@@ -73,16 +73,17 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(F.ABI_SYMBOLS) | set(F.HOST_SYMBOLS), declared ^ (set(F.ABI_SYMBOLS) | set(F.HOST_SYMBOLS))
     for name in sorted(declared):
         assert hasattr(L, name), name
-    assert L.rt_abi_version() == 1
+    assert L.rt_abi_version() == 2
     # the shared object really contains gfx950 code
     blob = open(F.LIB_PATH, "rb").read()
     assert b"amdgcn-amd-amdhsa--gfx950" in blob
     # every kernel instance the launch tables of abi.hip can pick is in the library: the six shading / tail
     # instances (feature masks of shading.h: kFeatVariants), the traversal kernel with and without counters / simple leaves
     for feat in (0, 1, 2, 3, 7, 19, 23, 15, 31):
-        assert b"_ZN3rtd7k_shadeILi%dEEE" % feat in blob and b"_ZN3rtd6k_tailILi%dEEE" % feat in blob
+        assert b"_ZN3rtd7k_shadeILi%dEEE" % feat in blob
+        assert b"_ZN3rtd6k_tailILi%dELb0EEE" % feat in blob and b"_ZN3rtd6k_tailILi%dELb1EEE" % feat in blob
     for inst in (b"k_traceILb0ELb0E", b"k_traceILb0ELb1E", b"k_traceILb1ELb0E", b"k_intersect_batch", b"k_generate",
-                 b"k_resolve", b"k_tonemap", b"kb_scatter", b"kb_emit"):
+                 b"k_resolve", b"k_tonemap", b"kb_scatter", b"kb_emit", b"k_film_pack", b"k_film_unpack"):
         assert inst in blob, inst
 
 
@@ -95,8 +96,8 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(F.rt_light) == 64
     assert C.sizeof(F.rt_camera) == 15 * 8 + 9 * 8
     assert C.sizeof(F.rt_ray) == 64 and C.sizeof(F.rt_hit) == 16
-    assert C.sizeof(F.rt_render_cfg) == 72
-    assert C.sizeof(F.rt_stats) == 8 * 8 + 16 + 8 + 32
+    assert C.sizeof(F.rt_render_cfg) == 80
+    assert C.sizeof(F.rt_stats) == 8 * 8 + 16 + 8 + 32 + 16 + 16
 
 
 def test_error_behaviour_without_compute():
@@ -104,7 +105,12 @@ def test_error_behaviour_without_compute():
     assert L.rt_context_create(None, 1, None) == F.RT_ERR_INVALID_ARG
     assert b"null" in L.rt_last_error()
     h = C.c_void_p()
-    assert L.rt_context_create(None, 2, C.byref(h)) == F.RT_ERR_UNSUPPORTED
+    assert L.rt_context_create(None, 2, C.byref(h)) == F.RT_ERR_INVALID_ARG  # device_ids missing
+    assert L.rt_context_create((C.c_int * 2)(0, 0), -1, C.byref(h)) == F.RT_ERR_INVALID_ARG
+    # without a HIP device every context creation fails with RT_ERR_NO_DEVICE (never a CPU fallback)
+    import torch
+    if not torch.cuda.is_available():
+        assert L.rt_context_create((C.c_int * 2)(0, 0), 2, C.byref(h)) == F.RT_ERR_NO_DEVICE
     assert L.rt_scene_create(None, C.byref(h)) == F.RT_ERR_INVALID_ARG
     assert L.rt_scene_commit(None) == F.RT_ERR_INVALID_ARG
     with pytest.raises(rr.RtError) as ei:
