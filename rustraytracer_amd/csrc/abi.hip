@@ -442,6 +442,40 @@ struct HostLeafData {
 };
 static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cache);
 
+// The builder emits nodes depth-first.  Move the top of the tree -- the first `n_top` nodes met breadth-first from the
+// root, which every ray walks -- to the front, in that order: they then share a few cache lines, and a kernel can hold
+// them on chip (k_trace's RT_LDS_NODES experiment).  Pure renumbering: the tree and every box stay what they were.
+static void top_of_tree_first(std::vector<DevNode>& nodes, uint32_t n_top) {
+    const uint32_t n = (uint32_t)nodes.size();
+    if (n < 2) return;
+    std::vector<uint32_t> order;  // new index -> old index
+    std::vector<uint32_t> new_of(n, 0xffffffffu);
+    order.reserve(n);
+    order.push_back(0);
+    new_of[0] = 0;
+    for (size_t q = 0; q < order.size() && order.size() < n_top; q++)
+        for (int k = 0; k < 4; k++) {
+            const int32_t c = nodes[order[q]].child[k];
+            if (c >= 0 && new_of[c] == 0xffffffffu && order.size() < n_top) {
+                new_of[c] = (uint32_t)order.size();
+                order.push_back((uint32_t)c);
+            }
+        }
+    for (uint32_t i = 0; i < n; i++)
+        if (new_of[i] == 0xffffffffu) {
+            new_of[i] = (uint32_t)order.size();
+            order.push_back(i);
+        }
+    std::vector<DevNode> out(n);
+    for (uint32_t i = 0; i < n; i++) {
+        DevNode nd = nodes[order[i]];
+        for (int k = 0; k < 4; k++)
+            if (nd.child[k] >= 0) nd.child[k] = (int32_t)new_of[nd.child[k]];
+        out[i] = nd;
+    }
+    nodes.swap(out);
+}
+
 int rt_scene_commit_ex(rt_scene* s, uint32_t flags) {
     SCENE_MUTABLE(s);
     if (flags & ~(uint32_t)RT_COMMIT_DEVICE_LBVH) return fail(RT_ERR_INVALID_ARG, "unknown commit flags 0x%x", flags);
@@ -602,6 +636,7 @@ static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cac
             }
         }
         cache.nodes = std::move(bvh.nodes);
+        top_of_tree_first(cache.nodes, 256);
         cache.depth = bvh.depth;
         cache.n_tri = n_tri_host;
         cache.valid = true;

@@ -452,10 +452,17 @@ struct TravCount {
 #endif
 constexpr int kLdsStack = RT_LDS_STACK;
 constexpr int kOvfStack = 3 * kMaxBvhDepth + 2 - kLdsStack;  // a 4-wide node pushes up to three children
+#ifndef RT_LDS_NODES
+#define RT_LDS_NODES 0
+#endif
 struct TravStack {
     int2* lds;       // &lds_stack[0][threadIdx.x], stride = blockDim.x entries
     int lds_stride;  // threads per block
     int32_t ovf[kOvfStack];
+#if RT_LDS_NODES > 0
+    const DevNode* top_nodes = nullptr;  // LDS copy of nodes[0, n_top) (k_trace only)
+    uint32_t n_top = 0;
+#endif
 };
 RTD void stack_push(TravStack& ts, int sp, int32_t node, float t) {
     if (sp < kLdsStack)
@@ -572,7 +579,12 @@ template <bool COUNT>
 RTD void node_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
     // near / far plane rows of the node picked by the direction signs (rows: lo_x lo_y lo_z hi_x hi_y hi_z,
     // 16 B each), so no per-value select is needed
+#if RT_LDS_NODES > 0
+    const char* nb = (uint32_t)tv.cur < ts.n_top ? reinterpret_cast<const char*>(&ts.top_nodes[tv.cur])
+                                                   : reinterpret_cast<const char*>(&sc.nodes[tv.cur]);
+#else
     const char* nb = reinterpret_cast<const char*>(&sc.nodes[tv.cur]);
+#endif
     const uint32_t kx = (__float_as_uint(tv.ix) >> 31) * 48u, ky = (__float_as_uint(tv.iy) >> 31) * 48u,
                    kz = (__float_as_uint(tv.iz) >> 31) * 48u;
     const float4 nx = *reinterpret_cast<const float4*>(nb + kx);

@@ -245,6 +245,21 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
     TravStack ts;
     ts.lds = &lds_stack[threadIdx.x];
     ts.lds_stride = 256;
+#if RT_LDS_NODES > 0
+    // (experiment, BASELINE north_star: "BVH-node tiles staged in LDS") the first RT_LDS_NODES nodes -- the top of the
+    // tree, which rt_scene_commit lays out breadth-first -- are copied into LDS once per block; node_step fetches
+    // them through a generic pointer (one flat load serves both the LDS and the HBM lanes of a round)
+    __shared__ DevNode lds_nodes[RT_LDS_NODES];
+    {
+        const uint32_t n_top = sc.n_nodes < (uint32_t)RT_LDS_NODES ? sc.n_nodes : (uint32_t)RT_LDS_NODES;
+        const float4* src = reinterpret_cast<const float4*>(sc.nodes);
+        float4* dst = reinterpret_cast<float4*>(lds_nodes);
+        for (uint32_t i = threadIdx.x; i < n_top * 8u; i += 256u) dst[i] = src[i];
+        __syncthreads();
+        ts.top_nodes = lds_nodes;
+        ts.n_top = n_top;
+    }
+#endif
     Trav tv;
     tv.done = true;
     tv.cur = 0;
@@ -458,9 +473,24 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool va
     const uint32_t fl_raw = in.flags[ls];
     const D3 l_in = ld3(in.lx, in.ly, in.lz, ls), o_in = ld3(in.ox, in.oy, in.oz, ls);
     const D3 d_in = ld3(in.dx, in.dy, in.dz, ls), beta_in = ld3(in.bx, in.by, in.bz, ls);
-    const int32_t hp_in = in.hit_prim[ls], sh_in = in.sh_prim[ls], pp_in = in.pr_prim[ls];
+    const int32_t hp_in = in.hit_prim[ls];
     const uint32_t hs_in = in.hit_slot[ls];
+#ifdef RT_SHADE_COND_NEE
+    // (experiment) the pending-light block (80 of the slot's 244 bytes) only for slots that carry pending terms:
+    // a fresh camera sample and a path whose last vertex found no light to sample have none
+    int32_t sh_in = -1, pp_in = -1;
+    D3 a_in = black(), q_in = black(), k_in = black();
+    if (valid && (fl_raw & (kHasShadow | kHasProbe)) && !(fl_raw & kDead)) {
+        sh_in = in.sh_prim[ls];
+        pp_in = in.pr_prim[ls];
+        a_in = ld3(in.ax, in.ay, in.az, ls);
+        q_in = ld3(in.qx, in.qy, in.qz, ls);
+        k_in = ld3(in.kx, in.ky, in.kz, ls);
+    }
+#else
+    const int32_t sh_in = in.sh_prim[ls], pp_in = in.pr_prim[ls];
     const D3 a_in = ld3(in.ax, in.ay, in.az, ls), q_in = ld3(in.qx, in.qy, in.qz, ls), k_in = ld3(in.kx, in.ky, in.kz, ls);
+#endif
     a.rng = in.rng[ls];
     a.orig = in.orig[ls];
     a.fl = valid ? fl_raw : kDead;
@@ -696,8 +726,11 @@ __global__ __launch_bounds__(256, FEAT <= RT_SHADE4_MAXFEAT ? 4 : (feat_three_wa
     // at 24-35 active lanes of 64 (PMC).  Paths are independent and the film staging is indexed by
     // (pixel, sample), so the order inside a block changes no result.  Scenes with Lambertian materials only
     // (FEAT == 0, e.g. C2) have nothing to separate and skip it; C3 +3.8 %, C4 +2.7 %, material_hdr(1) +2.9 %.
+#ifndef RT_SORT_FEAT0
+#define RT_SORT_FEAT0 0
+#endif
     uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (FEAT != 0) {
+    if (FEAT != 0 || RT_SORT_FEAT0) {
         constexpr uint32_t kCls = RT_SORT_CLASSES;
         __shared__ uint32_t s_cls[4][kCls];
         __shared__ uint16_t s_perm[256];

@@ -14,7 +14,7 @@ for line in sys.stdin:
         cur = m.group(1)
         rows[cur] = {}
         continue
-    m = re.search(r"remark: [^:]+:\d+:\d+:\s+([A-Za-z ]+?)(?: \[[^\]]+\])?: (\d+)", line)
+    m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]+\])?: (\d+)", line)
     if m and cur:
         rows[cur][m.group(1).strip()] = int(m.group(2))
 names = list(rows)
