@@ -1,4 +1,9 @@
-// ORACLE -- TEST INFRASTRUCTURE ONLY (see vecmath.h header).  PARITY UNPINNED.
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see vecmath.h header).  Bit-level PARITY UNPINNED: the reference has no
+// tests, fixtures or seedable output.  What ties this restatement to the reference:
+//   tests/test_reference_png_pin.py  region statistics of the reference's own examples/cornell_statue.png
+//   tests/test_lobe_tables.py        independent mpmath tables for every lobe's f / pdf / sample_f
+//   tests/test_oracle_arms.py        uv-mesh hit records and triangle emitters against numpy / quadrature
+//   tests/test_oracle_kat.py         hand-derived known-answer tests
 //
 // oracle.cpp -- CPU restatement (C++17, f64) of the reference's path-tracing hot
 // path, quirks included, with the injectable counter RNG of

@@ -1,4 +1,5 @@
-/* ORACLE -- TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see oracle.cpp header).
+/* ORACLE -- TEST INFRASTRUCTURE ONLY.  Bit-level PARITY UNPINNED; pinned statistically to the reference's
+ * examples/cornell_statue.png and to independent lobe tables (see oracle.cpp header).
  * C entry points of liboracle.so, loaded by tests/, smoke() and bench.py's
  * cpu_baseline leg through ctypes.  Scenes arrive as the same flattened POD
  * arrays the product's C ABI takes (include/rt_abi.h).                        */
