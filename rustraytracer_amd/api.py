@@ -152,6 +152,7 @@ class Context:
         hits = (F.rt_hit * n)()
         _check(F.lib().rt_intersect_batch(self._h, gscene._h, rays, n, hits))
         ha = np.frombuffer(hits, dtype=np.dtype([("t", "<f8"), ("prim", "<i4"), ("r", "<u4")]))
+        self.last_intersect_cost = ha["r"].copy()  # nodes | tris << 8 | others << 16 per ray (saturating bytes)
         return ha["t"].copy(), ha["prim"].copy()
 
     def resolve_rgb8(self, rgb_sum, n):

@@ -20,6 +20,7 @@
 #include "bvh_gpu.h"
 #include "env_dist.h"
 #include "device/kernels.hip"
+#include "build/f32/kernels.hip"  // generated: the same kernels in binary32, namespace rtd32 (tools/make_f32_sources.py)
 
 using namespace rtd;
 
@@ -686,6 +687,49 @@ int rt_scene_get_info(const rt_scene* s, rt_scene_info* out) {
     return RT_OK;
 }
 
+// RT_PRECISION_F32: leaf-ordered vertices / normals as floats; a sphere / rect slot keeps its {kind, transform} word
+// bit for bit in floats 5 and 6 (scene_dev.h)
+__global__ __launch_bounds__(256) void k_leaf_to_f32(const double* __restrict__ tri, const double* __restrict__ nrm,
+                                                    const uint32_t* __restrict__ leaf_prim, uint32_t n, float* tri32,
+                                                    float* nrm32) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* t = tri + (size_t)i * 9;
+    float* o = tri32 + (size_t)i * 9;
+    if (leaf_prim[i] & kLeafOther) {
+        for (int k = 0; k < 5; k++) o[k] = (float)t[k];
+        const unsigned long long meta = (unsigned long long)__double_as_longlong(t[5]);
+        o[5] = __uint_as_float((uint32_t)(meta & 0xffffffffull));
+        o[6] = __uint_as_float((uint32_t)(meta >> 32));
+        o[7] = o[8] = 0.0f;
+    } else {
+        for (int k = 0; k < 9; k++) o[k] = (float)t[k];
+    }
+    if (nrm32)
+        for (int k = 0; k < 9; k++) nrm32[(size_t)i * 9 + k] = (float)nrm[(size_t)i * 9 + k];
+}
+
+// First fast-mode use of a scene: binary32 copies of the leaf-ordered vertices / normals (scene_dev.h).  Every entry
+// that launches rtd32 traversal code calls this first -- those kernels read leaf_tri32 unconditionally.
+static int ensure_f32_leaves(rt_scene* s, hipStream_t stream) {
+    if (s->dev.leaf_tri32 || !s->dev.n_prims) return RT_OK;
+    const size_t nflt = (size_t)s->dev.n_prims * 9;
+    float *t32 = nullptr, *n32 = nullptr;
+    HIP_TRY(hipMalloc((void**)&t32, nflt * sizeof(float)));
+    s->allocs.push_back(t32);
+    if (s->dev.leaf_nrm) {
+        HIP_TRY(hipMalloc((void**)&n32, nflt * sizeof(float)));
+        s->allocs.push_back(n32);
+    }
+    hipLaunchKernelGGL(k_leaf_to_f32, dim3((unsigned)((s->dev.n_prims + 255) / 256)), dim3(256), 0, stream, s->dev.leaf_tri,
+                       s->dev.leaf_nrm, s->dev.leaf_prim, s->dev.n_prims, t32, n32);
+    HIP_TRY(hipGetLastError());
+    s->dev.leaf_tri32 = t32;
+    s->dev.leaf_nrm32 = n32;
+    s->info.device_bytes_total += nflt * sizeof(float) * (n32 ? 2 : 1);
+    return RT_OK;
+}
+
 static uint32_t next_pow2(uint32_t v) {  // sampler.rs:633-642
     uint32_t p = 1;
     while (p < v) p <<= 1;
@@ -713,6 +757,8 @@ struct RenderJob {
     std::atomic<bool> cancelled{false};  // rt_render_cfg.cancel was seen non-zero
     int trace_blocks;
     bool count_trav;
+    bool f32;  // RT_PRECISION_F32: the binary32 kernel set
+    bool f32_gen, f32_trace, f32_shade, f32_tail;  // (debug: RT_F32_MIX picks the kernels that use it)
 };
 
 static int lane_fail(Lane& ln, int code, const char* fmt, ...) {
@@ -736,36 +782,42 @@ typedef void (*ShadeKernel)(DevScene, PathState, PathState, Ctl*, uint32_t, uint
                             DevStats*);
 typedef void (*TailKernel)(DevScene, PathState, PathState, Ctl*, uint32_t, uint32_t, double*, double*, double*,
                            DevStats*);
-static ShadeKernel shade_kernel(int v) {
-    switch (v) {
-        case 0: return k_shade<kFeatVariants[0]>;
-        case 1: return k_shade<kFeatVariants[1]>;
-        case 2: return k_shade<kFeatVariants[2]>;
-        case 3: return k_shade<kFeatVariants[3]>;
-        case 4: return k_shade<kFeatVariants[4]>;
-        case 5: return k_shade<kFeatVariants[5]>;
-        case 6: return k_shade<kFeatVariants[6]>;
-        case 7: return k_shade<kFeatVariants[7]>;
-        default: return k_shade<kFeatVariants[8]>;
+typedef void (*TraceKernel)(DevScene, PathState, const uint32_t*, Ctl*, uint32_t, DevStats*, TraceTune, MirrorEntry*,
+                            uint32_t, const BatchCtl*, unsigned long long);
+typedef void (*GenKernel)(PathState, rt_camera, ChunkDesc, const uint32_t*, uint32_t*, const Ctl*);
+// The kernels exist twice: namespace rtd (binary64, the parity mode) and namespace rtd32 (the same sources in
+// binary32, RT_PRECISION_F32).  Path state, film staging and scene records are the same f64 arrays in both, so
+// the launch schedule below does not care which set it drives.
+#define RT_FEAT_SWITCH(NS, KERNEL, ...)                                        \
+    switch (v) {                                                               \
+        case 0: return NS::KERNEL<kFeatVariants[0] __VA_ARGS__>;               \
+        case 1: return NS::KERNEL<kFeatVariants[1] __VA_ARGS__>;               \
+        case 2: return NS::KERNEL<kFeatVariants[2] __VA_ARGS__>;               \
+        case 3: return NS::KERNEL<kFeatVariants[3] __VA_ARGS__>;               \
+        case 4: return NS::KERNEL<kFeatVariants[4] __VA_ARGS__>;               \
+        case 5: return NS::KERNEL<kFeatVariants[5] __VA_ARGS__>;               \
+        case 6: return NS::KERNEL<kFeatVariants[6] __VA_ARGS__>;               \
+        case 7: return NS::KERNEL<kFeatVariants[7] __VA_ARGS__>;               \
+        default: return NS::KERNEL<kFeatVariants[8] __VA_ARGS__>;              \
     }
+#define RT_COMMA ,
+static ShadeKernel shade_kernel(int v, bool f32) {
+    if (f32) RT_FEAT_SWITCH(rtd32, k_shade)
+    RT_FEAT_SWITCH(rtd, k_shade)
 }
-extern "C++" {
-template <bool COUNT>
-static TailKernel tail_kernel_c(int v) {
-    switch (v) {
-        case 0: return k_tail<kFeatVariants[0], COUNT>;
-        case 1: return k_tail<kFeatVariants[1], COUNT>;
-        case 2: return k_tail<kFeatVariants[2], COUNT>;
-        case 3: return k_tail<kFeatVariants[3], COUNT>;
-        case 4: return k_tail<kFeatVariants[4], COUNT>;
-        case 5: return k_tail<kFeatVariants[5], COUNT>;
-        case 6: return k_tail<kFeatVariants[6], COUNT>;
-        case 7: return k_tail<kFeatVariants[7], COUNT>;
-        default: return k_tail<kFeatVariants[8], COUNT>;
+static TailKernel tail_kernel(int v, bool count, bool f32) {
+    if (f32) {
+        if (count) RT_FEAT_SWITCH(rtd32, k_tail, RT_COMMA true)
+        RT_FEAT_SWITCH(rtd32, k_tail, RT_COMMA false)
     }
+    if (count) RT_FEAT_SWITCH(rtd, k_tail, RT_COMMA true)
+    RT_FEAT_SWITCH(rtd, k_tail, RT_COMMA false)
 }
-}  // extern "C++"
-static TailKernel tail_kernel(int v, bool count) { return count ? tail_kernel_c<true>(v) : tail_kernel_c<false>(v); }
+static TraceKernel trace_kernel(bool count, bool simple, bool f32) {
+    if (f32) return count ? rtd32::k_trace<true, false> : (simple ? rtd32::k_trace<false, true> : rtd32::k_trace<false, false>);
+    return count ? rtd::k_trace<true, false> : (simple ? rtd::k_trace<false, true> : rtd::k_trace<false, false>);
+}
+static GenKernel generate_kernel(bool f32) { return f32 ? rtd32::k_generate : rtd::k_generate; }
 
 // One lane's share of a batch: keep `pool` paths alive, topping up from the shared batch counter,
 // until the batch is exhausted and this lane's paths have all retired.
@@ -836,7 +888,7 @@ static int run_lane(RenderJob& job, int lane_id) {
                     // few paths left: one fused launch finishes them (k_tail) instead of ~2 launches per bounce
                     // that are each as slow as their single longest ray
                                         const uint32_t tail_blocks = std::min((live + 255) / 256, (uint32_t)c->num_cus * 2u);  // persistent waves
-                    hipLaunchKernelGGL(tail_kernel(job.s->shade_variant, job.count_trav), dim3(tail_blocks), dim3(256), 0, stream, job.s->dev, ln.st[0],
+                    hipLaunchKernelGGL(tail_kernel(job.s->shade_variant, job.count_trav, job.f32_tail), dim3(tail_blocks), dim3(256), 0, stream, job.s->dev, ln.st[0],
                                        ln.st[1], ln.ctl, (uint32_t)it, cfg->max_depth, c->lf[0], c->lf[1], c->lf[2],
                                        c->stats);
                     break;
@@ -846,7 +898,7 @@ static int run_lane(RenderJob& job, int lane_id) {
         // top up the pool with new camera samples, then trace and shade everything alive
         hipLaunchKernelGGL(k_plan, dim3(1), dim3(1), 0, stream, ln.ctl, c->batch, (uint32_t)it, P, job.batch_total, c->stats);
         if (!exhausted_known)
-            hipLaunchKernelGGL(k_generate, dim3(gen_blocks), dim3(256), 0, stream, ln.st[it & 1], job.cam, job.batch,
+            hipLaunchKernelGGL(generate_kernel(job.f32_gen), dim3(gen_blocks), dim3(256), 0, stream, ln.st[it & 1], job.cam, job.batch,
                                c->pix_list, ln.queue[it & 1], ln.ctl);
         const uint32_t shade_blocks = std::max(1u, (bound_active + 255) / 256);
         const uint32_t tblocks = std::max(
@@ -862,20 +914,15 @@ static int run_lane(RenderJob& job, int lane_id) {
             LANE_TRY(hipEventRecord(a, stream));
         }
         const uint32_t seq = seq0 + (uint32_t)it;
-        if (job.count_trav)
-            hipLaunchKernelGGL((k_trace<true, false>), dim3(tblocks), dim3(256), 0, stream, job.s->dev, ln.st[it & 1],
-                               ln.queue[it & 1], ln.ctl, (uint32_t)it, c->stats, c->tune, no_mirror ? nullptr : ln.mirror_d, seq, c->batch,
-                               job.batch_total);
-        else
-            hipLaunchKernelGGL((job.s->dev.simple_others ? k_trace<false, true> : k_trace<false, false>), dim3(tblocks), dim3(256), 0, stream, job.s->dev, ln.st[it & 1],
-                               ln.queue[it & 1], ln.ctl, (uint32_t)it, c->stats, c->tune, no_mirror ? nullptr : ln.mirror_d, seq, c->batch,
-                               job.batch_total);
+        hipLaunchKernelGGL(trace_kernel(job.count_trav, job.s->dev.simple_others != 0, job.f32_trace), dim3(tblocks), dim3(256), 0, stream,
+                           job.s->dev, ln.st[it & 1], ln.queue[it & 1], ln.ctl, (uint32_t)it, c->stats, c->tune,
+                           no_mirror ? nullptr : ln.mirror_d, seq, c->batch, job.batch_total);
         if (!no_ev) {
             LANE_TRY(hipEventRecord(b, stream));
             ln.trace_ev.emplace_back(a, b);
         }
         ln.trace_launches++;
-        hipLaunchKernelGGL(shade_kernel(job.s->shade_variant), dim3(shade_blocks), dim3(256), 0, stream, job.s->dev, ln.st[it & 1],
+        hipLaunchKernelGGL(shade_kernel(job.s->shade_variant, job.f32_shade), dim3(shade_blocks), dim3(256), 0, stream, job.s->dev, ln.st[it & 1],
                            ln.st[(it + 1) & 1], ln.ctl, (uint32_t)it, cfg->max_depth, ln.queue[(it + 1) & 1], c->lf[0],
                            c->lf[1], c->lf[2], c->stats);
         if (!no_ev) {  // the shading kernel runs from event b (end of k_trace) to this one
@@ -997,10 +1044,21 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
         job.pool = P;
         job.count_trav = (cfg->flags & RT_RENDER_COUNT_TRAVERSAL) != 0;
         // persistent grid = what is resident at once (more blocks would only queue behind them)
-        int occ_t = 0, occ_c = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_t, s->dev.simple_others ? k_trace<false, true> : k_trace<false, false>, 256, 0));
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, k_trace<true, false>, 256, 0));
-        int per_cu = std::max(1, job.count_trav ? occ_c : occ_t);
+        job.f32 = cfg->precision == RT_PRECISION_F32;
+        job.f32_gen = job.f32_trace = job.f32_shade = job.f32_tail = job.f32;
+        if (job.f32) {
+            const int frc = ensure_f32_leaves(s, stream);
+            if (frc != RT_OK) return frc;
+        }
+        if (const char* e = getenv("RT_F32_MIX")) {  // debug: e.g. "t" = only the traversal kernel in f32
+            job.f32_gen = job.f32 && strchr(e, 'g');
+            job.f32_trace = job.f32 && strchr(e, 't');
+            job.f32_shade = job.f32 && strchr(e, 's');
+            job.f32_tail = job.f32 && strchr(e, 'l');
+        }
+        int occ = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, trace_kernel(job.count_trav, s->dev.simple_others != 0, job.f32), 256, 0));
+        int per_cu = std::max(1, occ);
         if (const char* e = getenv("RT_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));
         job.trace_blocks = c->num_cus * per_cu;
         size_t ev_i = 0;
@@ -1298,7 +1356,8 @@ static int check_render_args(rt_context* c, rt_scene* s, const rt_camera* cam, c
     if (cfg->width == 0 || cfg->height == 0 || cfg->spp == 0) return fail(RT_ERR_INVALID_ARG, "rt_render: empty image or spp == 0");
     if ((uint64_t)cfg->width * cfg->height >= (1ull << 30)) return fail(RT_ERR_UNSUPPORTED, "rt_render: image too large");
     if (cfg->max_depth > 255) return fail(RT_ERR_UNSUPPORTED, "rt_render: max_depth > 255");
-    if (cfg->precision != RT_PRECISION_F64) return fail(RT_ERR_UNSUPPORTED, "rt_render: unknown precision");
+    if (cfg->precision != RT_PRECISION_F64 && cfg->precision != RT_PRECISION_F32)
+        return fail(RT_ERR_UNSUPPORTED, "rt_render: unknown precision");
     if (!(cfg->x1 == 0 && cfg->y1 == 0) &&
         (cfg->x1 > cfg->width || cfg->y1 > cfg->height || cfg->x0 > cfg->x1 || cfg->y0 > cfg->y1))
         return fail(RT_ERR_INVALID_ARG, "rt_render: bad pixel window");
@@ -1373,7 +1432,11 @@ int rt_intersect_batch(rt_context* c, rt_scene* s, const rt_ray* rays, uint64_t 
     int rc = RT_OK;
     e = hipMemcpyAsync(d_rays, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_intersect_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, s->dev, d_rays, n, d_hits);
+        // (debug / tests: RT_INTERSECT_F32=1 runs the fast-mode traversal on the same rays)
+        if (getenv("RT_INTERSECT_F32") && ensure_f32_leaves(s, c->stream) == RT_OK)
+            hipLaunchKernelGGL(rtd32::k_intersect_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, s->dev, d_rays, n, d_hits);
+        else
+            hipLaunchKernelGGL(rtd::k_intersect_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, s->dev, d_rays, n, d_hits);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(hits, d_hits, n * sizeof(rt_hit), hipMemcpyDeviceToHost, c->stream);

@@ -13,8 +13,28 @@
 #define RTD __device__ __forceinline__
 #define RTDN __device__ __noinline__
 
+// Values that stay binary64 in the f32 fast mode too: everything that lives in HBM (scene records of the ABI, path
+// state, film staging, the film).  tools/make_f32_sources.py turns every other `double` of the device sources into
+// `float` when it generates the fast-mode kernels (namespace rtd32); these two typedefs are left alone.
+typedef double f64_t;     // RT_KEEP_F64
+typedef double2 f64x2_t;  // RT_KEEP_F64
+
 namespace rtd {
 
+#ifdef RT_F32
+// ---- fast mode: hardware-rate single-precision elementary functions (not part of the numerical contract)
+#undef dm_sin
+#undef dm_cos
+#undef dm_atan2
+#undef dm_acos
+#undef dm_log
+RTD double dm_sin(double x) { return ::sinf(x); }
+RTD double dm_cos(double x) { return ::cosf(x); }
+RTD double dm_atan2(double y, double x) { return ::atan2f(y, x); }
+RTD double dm_acos(double x) { return ::acosf(x); }
+RTD double dm_log(double x) { return ::logf(x); }
+RTD double dm_sqrt(double x) { return __builtin_sqrt(x); }
+#else
 // The elementary functions are called from dozens of sites of the shading code; inlined everywhere they blew
 // the shading kernels up to 170-290 KB of code against a 64 KB instruction cache.  One out-of-line copy each:
 #ifndef RT_INLINE_MATH
@@ -28,6 +48,7 @@ RTDN double ni_log(double x) { return dm_log(x); }
 #define dm_atan2 ni_atan2
 #define dm_acos ni_acos
 #define dm_log ni_log
+#endif
 #endif
 
 // consts.rs:30-42
@@ -75,7 +96,11 @@ RTD uint64_t rng_init(uint64_t seed, uint64_t pixel, uint64_t sample) {
 }
 RTD double rng_next(uint64_t& s) {
     s += RT_RNG_G;
+#ifdef RT_F32
+    return (double)(uint32_t)(rng_mix(s) >> 40) * (1.0 / 16777216.0);  // the top 24 bits of the same draw
+#else
     return (double)(rng_mix(s) >> 11) * (1.0 / 9007199254740992.0);
+#endif
 }
 
 }  // namespace rtd

@@ -45,11 +45,11 @@ RTD void make_coordinate_system(D3 v1, D3& v2, D3& v3) {
 }
 RTD D3 face_forward(D3 n, D3 v) { return dot(n, v) < 0.0 ? -n : n; }  // util.rs:578-581
 
-RTD D3 xf_point(const double* m, D3 p) {
+RTD D3 xf_point(const f64_t* m, D3 p) {
     return d3(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
               m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]);
 }
-RTD D3 xf_vector(const double* m, D3 v) {
+RTD D3 xf_vector(const f64_t* m, D3 v) {
     return d3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z,
               m[8] * v.x + m[9] * v.y + m[10] * v.z);
 }
@@ -267,13 +267,21 @@ RTD bool tri_record(const DevScene& sc, const rt_primitive& pr, D3 o, D3 dir, do
 }
 // The same record from the triangle's leaf slot (meshes without uvs: default uvs of hittable.rs:455-460)
 RTD bool tri_record_slot(const DevScene& sc, uint32_t ls, int32_t pi, D3 o, D3 dir, double tmax, HitRec& h) {
-    const double* tp = sc.leaf_tri + (size_t)ls * 9;
+#ifdef RT_F32
+    const float* tp = sc.leaf_tri32 + (size_t)ls * 9;  // RT_KEEP_F64 (the line is already in its fast-mode form)
+#else
+    const f64_t* tp = sc.leaf_tri + (size_t)ls * 9;
+#endif
     const LeafMeta meta = sc.leaf_meta[ls];
     const D3 p0 = d3(tp[0], tp[1], tp[2]), p1 = d3(tp[3], tp[4], tp[5]), p2 = d3(tp[6], tp[7], tp[8]);
     const bool has_n = (meta.mat_flags & kMetaHasNormals) != 0u;
     D3 n1 = d3(0, 0, 0), n2 = n1, n3 = n1;
     if (has_n) {
-        const double* np = sc.leaf_nrm + (size_t)ls * 9;
+#ifdef RT_F32
+        const float* np = sc.leaf_nrm32 + (size_t)ls * 9;  // RT_KEEP_F64
+#else
+        const f64_t* np = sc.leaf_nrm + (size_t)ls * 9;
+#endif
         n1 = d3(np[0], np[1], np[2]);
         n2 = d3(np[3], np[4], np[5]);
         n3 = d3(np[6], np[7], np[8]);
@@ -316,6 +324,9 @@ RTD bool rect_core_v(const DevScene& sc, uint32_t kind, double a0, double b0, do
         b = to.z + t * td.z;
     }
     if (a < a0 || b < b0 || a > a1 || b > b1) return false;
+#ifdef RT_F32
+    if (t != t || a != a || b != b) return false;  // fast mode: a ray in the rect's plane (0 / 0) is a miss, not a NaN hit
+#endif
     return true;
 }
 RTD bool rect_core(const DevScene& sc, const rt_primitive& pr, D3 o, D3 dir, double t0, double t1, double& t,
@@ -529,7 +540,20 @@ RTD void node_consts(Trav& tv, D3 o, D3 inv) {
 }
 
 RTD void trav_init(Trav& tv, const DevScene& sc, D3 o, D3 dir, double tmin, double tmax) {
+#ifdef RT_F32
+    // Fast mode only.  In binary32 a direction component is EXACTLY zero every few hundred thousand rays (e.g.
+    // to.x - origin.x of the camera rays near the image's centre column cancels to 0): 1/0 = inf makes the slab
+    // tests of that axis NaN, i.e. unconstrained (the reference's Q5 behaviour, practically unreachable in f64), and
+    // such a ray then walks a whole slice of the tree -- thousands of steps that the launch's other waves wait
+    // for.  The reciprocal is therefore taken of a component pushed away from zero (relative 1e-12).
+    const double dmax = rmax(absd(dir.x), rmax(absd(dir.y), absd(dir.z))), deps = rmax(dmax * 1e-12, 1e-30);
+    const D3 dsafe = d3(absd(dir.x) < deps ? __builtin_copysign(deps, dir.x) : dir.x,
+                        absd(dir.y) < deps ? __builtin_copysign(deps, dir.y) : dir.y,
+                        absd(dir.z) < deps ? __builtin_copysign(deps, dir.z) : dir.z);
+    const D3 inv = d3(1.0 / dsafe.x, 1.0 / dsafe.y, 1.0 / dsafe.z);
+#else
     const D3 inv = d3(1.0 / dir.x, 1.0 / dir.y, 1.0 / dir.z);
+#endif
     tv.trr = tri_ray(dir);
     tv.op = permute(o, tv.trr);
     tv.ip = permute(inv, tv.trr);
@@ -657,7 +681,11 @@ RTD void leaf_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
     const uint32_t first = (code & ~kLeafCodeOther) >> 3, count = (code & 7u) + 1u;
     const uint32_t slot = first;
     const uint32_t e = sc.leaf_prim[slot];
-    const double* tvp = sc.leaf_tri + (size_t)slot * 9;
+#ifdef RT_F32
+    const float* tvp = sc.leaf_tri32 + (size_t)slot * 9;  // RT_KEEP_F64
+#else
+    const f64_t* tvp = sc.leaf_tri + (size_t)slot * 9;
+#endif
     double t = 0.0;
     int32_t pi = -1;
     bool hit = false;
@@ -665,9 +693,13 @@ RTD void leaf_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
         // The nine coordinates are fetched in the ray's permuted axis order (kx, ky, kz), so the sheared
         // test needs no per-triangle shuffle; the addresses do not depend on `e` (loads issue together).
         const int kz = tv.trr.kz, kx = kz == 2 ? 0 : kz + 1, ky = kx == 2 ? 0 : kx + 1;
-        const double* px = tvp + kx;
-        const double* py = tvp + ky;
-        const double* pz = tvp + kz;
+#ifdef RT_F32
+        const float *px = tvp + kx, *py = tvp + ky, *pz = tvp + kz;  // RT_KEEP_F64
+#else
+        const f64_t* px = tvp + kx;
+        const f64_t* py = tvp + ky;
+        const f64_t* pz = tvp + kz;
+#endif
         const D3 op = tv.op, ip = tv.ip;
         if (COUNT) tc->tris++;
         const D3 p0t = d3(px[0] - op.x, py[0] - op.y, pz[0] - op.z);
@@ -707,14 +739,19 @@ RTD void leaf_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
         // untransformed rect or a sphere needs no second, dependent fetch.  Their own AABB
         // (Primitive::get_bounding_box) is re-derived with the constructor's arithmetic
         // (primitive.rs:66-68, 110-113, 161-164, 212-215): k -/+ SMALL, centre -/+ r.
-        const double2 q0 = *reinterpret_cast<const double2*>(tvp);
-        const double2 q1 = *reinterpret_cast<const double2*>(tvp + 2);
-        const double2 q2 = *reinterpret_cast<const double2*>(tvp + 4);
         const D3 o = unpermute(tv.op, tv.trr.kz), inv = unpermute(tv.ip, tv.trr.kz);
         pi = (int32_t)(e & ~kLeafOther);
         if (COUNT) tc->others++;
+#ifdef RT_F32
+        const double v0 = tvp[0], v1 = tvp[1], v2 = tvp[2], v3 = tvp[3], v4 = tvp[4];
+        const uint64_t meta = (uint64_t)__float_as_uint(tvp[5]) | ((uint64_t)__float_as_uint(tvp[6]) << 32);
+#else
+        const f64x2_t q0 = *reinterpret_cast<const f64x2_t*>(tvp);
+        const f64x2_t q1 = *reinterpret_cast<const f64x2_t*>(tvp + 2);
+        const f64x2_t q2 = *reinterpret_cast<const f64x2_t*>(tvp + 4);
         const double v0 = q0.x, v1 = q0.y, v2 = q1.x, v3 = q1.y, v4 = q2.x;
         const uint64_t meta = dm_bits(q2.y);
+#endif
         const uint32_t kind = (uint32_t)(meta & 0xffu);
         const int32_t xform_index = (int32_t)(uint32_t)(meta >> 32) - 1;
         double bx0, by0, bz0, bx1, by1, bz1;
@@ -725,15 +762,18 @@ RTD void leaf_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
         } else if (!SIMPLE && kind == RT_PRIM_SPHERE) {
             bx0 = v0 - v3; by0 = v1 - v3; bz0 = v2 - v3;
             bx1 = v0 + v3; by1 = v1 + v3; bz1 = v2 + v3;
-        } else if (kind == RT_PRIM_XY_RECT) {
-            bx0 = v0; by0 = v1; bz0 = v4 - kSmall;
-            bx1 = v2; by1 = v3; bz1 = v4 + kSmall;
-        } else if (kind == RT_PRIM_XZ_RECT) {
-            bx0 = v0; by0 = v4 - kSmall; bz0 = v1;
-            bx1 = v2; by1 = v4 + kSmall; bz1 = v3;
         } else {
-            bx0 = v4 - kSmall; by0 = v0; bz0 = v1;
-            bx1 = v4 + kSmall; by1 = v2; bz1 = v3;
+            // xy: (v0, v1, k -/+ S), (v2, v3)   xz: (v0, k -/+ S, v1), (v2, .., v3)   yz: (k -/+ S, v0, v1), (.., v2, v3)
+            // Written with selects, not as an if-chain over the three kinds: hipcc (ROCm 7.2) compiled the chain's
+            // yz arm of the binary32 instance with by0 / bz0 left undefined (every yz rect was missed).
+            const double klo = v4 - kSmall, khi = v4 + kSmall;
+            const bool xy = kind == RT_PRIM_XY_RECT, xz = kind == RT_PRIM_XZ_RECT;
+            bx0 = (xy || xz) ? v0 : klo;
+            bx1 = (xy || xz) ? v2 : khi;
+            by0 = xy ? v1 : (xz ? klo : v0);
+            by1 = xy ? v3 : (xz ? khi : v2);
+            bz0 = xy ? klo : v1;
+            bz1 = xy ? khi : v3;
         }
         double en;
         if (slab(bx0, by0, bz0, bx1, by1, bz1, o, inv, tmin, tmax, en)) {

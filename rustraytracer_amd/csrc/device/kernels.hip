@@ -28,43 +28,28 @@
 
 namespace rtd {
 
-constexpr uint32_t kRing = 512;  // per-iteration counters live in a ring indexed by it % kRing
+// Ctl, BatchCtl, MirrorEntry, ChunkDesc, TraceTune, kRing: scene_dev.h (shared with the f32 kernels)
 
-struct Ctl {
-    uint32_t n_active[kRing];
-    uint32_t n_rays[kRing];
-    uint32_t head[kRing];
-    // written by k_plan for the k_generate that follows it
-    uint32_t gen_count, gen_first, gen_slot, gen_q;
-};
-
-// The batch being rendered, shared by both lanes.
-struct BatchCtl {
-    unsigned long long next;  // next camera sample (path index inside the batch) to generate
-};
-
-// Host-visible copy of the per-iteration counters (pinned, mapped memory).  k_trace(it) publishes
-// {n_active[it], n_rays[it]} when it STARTS; the host sizes the grids of iteration it+2 from it
-// (counts never grow) and stops launching once a published n_active is zero -- no stream sync.
-struct MirrorEntry {
-    uint32_t n_active, n_rays, seq, remaining;  // remaining: camera samples of the batch not yet generated (saturated)
-};
-
-struct ChunkDesc {
-    uint32_t n_pixels;     // pixels in this batch (PB)
-    uint32_t n_samples;    // samples per pixel in this batch
-    uint32_t pixel_base;   // offset into pix_list
-    uint32_t sample_base;  // first sample index
-    uint32_t width, height;
-    uint64_t seed;
-};
-
-RTD D3 ld3(const double* x, const double* y, const double* z, uint32_t i) { return d3(x[i], y[i], z[i]); }
-RTD void st3(double* x, double* y, double* z, uint32_t i, D3 v) {
+#ifdef RT_F32
+// Fast mode: the path state keeps its f64-sized slots (the launch schedule and the pools are shared with the parity
+// mode) but holds binary32 values in the low half of each slot -- no v_cvt_f32_f64 / v_cvt_f64_f32 per field and bounce.
+RTD D3 ld3(const f64_t* x, const f64_t* y, const f64_t* z, uint32_t i) {
+    return d3(reinterpret_cast<const float*>(x)[2u * i], reinterpret_cast<const float*>(y)[2u * i],  // RT_KEEP_F64
+              reinterpret_cast<const float*>(z)[2u * i]);                                            // RT_KEEP_F64
+}
+RTD void st3(f64_t* x, f64_t* y, f64_t* z, uint32_t i, D3 v) {
+    reinterpret_cast<float*>(x)[2u * i] = v.x;  // RT_KEEP_F64
+    reinterpret_cast<float*>(y)[2u * i] = v.y;  // RT_KEEP_F64
+    reinterpret_cast<float*>(z)[2u * i] = v.z;  // RT_KEEP_F64
+}
+#else
+RTD D3 ld3(const f64_t* x, const f64_t* y, const f64_t* z, uint32_t i) { return d3(x[i], y[i], z[i]); }
+RTD void st3(f64_t* x, f64_t* y, f64_t* z, uint32_t i, D3 v) {
     x[i] = v.x;
     y[i] = v.y;
     z[i] = v.z;
 }
+#endif
 
 // Wave-uniform fetch-and-add on the SCALAR memory path (s_atomic_add, gfx9 family incl. gfx950; checked against
 // vector atomics on the same word by tools/experiments/satomic_test.hip).  Its return travels through lgkmcnt, so
@@ -111,6 +96,7 @@ RTD void wave_count(bool pred, unsigned long long* counter) {
 RTD DevStats* stat_shard(DevStats* stats) { return stats + (blockIdx.x & (kStatShards - 1)); }
 
 // ------------------------------------------------------------------ generate
+#ifndef RT_F32  // (precision-independent: compiled once, in the f64 namespace)
 // k_plan (one thread): how many camera samples this lane starts now = free pool slots, limited by
 // what the batch still holds; reserves them from the shared batch counter and appends them to the
 // path list / ray queue of iteration `it`.  Also clears the ring entries of iteration it+2.
@@ -142,6 +128,8 @@ __global__ void k_plan(Ctl* ctl, BatchCtl* batch, uint32_t it, uint32_t pool, un
         atomicAdd(&stats->r1, want);
     }
 }
+
+#endif
 
 // integrator.rs:357-366 + sampler.rs:606-613 + geometry.rs:177-190 (+ util.rs:105-113)
 __global__ __launch_bounds__(256) void k_generate(PathState st, rt_camera cam, ChunkDesc ck,
@@ -200,13 +188,6 @@ __global__ __launch_bounds__(256) void k_generate(PathState st, rt_camera cam, C
 //     waiting for (majority scheduling): the wave never runs the primitive code for the sake of a few
 //     lanes while the rest are walking the tree, and vice versa.
 // Every wave leaves the loop once the queue is exhausted and its own lanes are done.
-struct TraceTune {
-    int refill_lanes;  // refill when at least this many lanes are idle (<= 64)
-    int node_bias;     // a node step runs when lanes_at_nodes * node_bias >= lanes_at_leaves * 4 (4 = plain majority)
-    int unused;
-    int reserve;       // queue entries a wave reserves per atomic (refills are served from the reservation)
-};
-
 template <bool COUNT, bool SIMPLE>
 __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, PathState st, const uint32_t* __restrict__ queue,
                                                Ctl* ctl, uint32_t it_abs, DevStats* stats, TraceTune tune,
@@ -405,12 +386,14 @@ __global__ __launch_bounds__(256) void k_intersect_batch(DevScene sc, const rt_r
     ts.lds = &lds_stack[threadIdx.x];
     ts.lds_stride = 256;
     double t;
-    const int32_t prim = closest_hit<false>(sc, d3(r.origin[0], r.origin[1], r.origin[2]),
-                                            d3(r.dir[0], r.dir[1], r.dir[2]), r.tmin, r.tmax, t, ts, &tc);
+    const int32_t prim = closest_hit<true>(sc, d3(r.origin[0], r.origin[1], r.origin[2]),
+                                           d3(r.dir[0], r.dir[1], r.dir[2]), r.tmin, r.tmax, t, ts, &tc);
     rt_hit h;
     h.t = prim >= 0 ? t : kInf;
     h.prim = prim;
-    h.reserved = 0;
+    // diagnostic: what the traversal of this ray cost (saturating bytes: nodes | triangles << 8 | spheres/rects << 16)
+    h.reserved = (tc.nodes > 255u ? 255u : tc.nodes) | ((tc.tris > 255u ? 255u : tc.tris) << 8) |
+                 ((tc.others > 255u ? 255u : tc.others) << 16);
     hits[i] = h;
 }
 
@@ -712,8 +695,8 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
 #endif
 template <int FEAT>
 __global__ __launch_bounds__(256, FEAT <= RT_SHADE4_MAXFEAT ? 4 : (feat_three_waves(FEAT) && RT_SHADE3_MAXFEAT >= 3 ? 3 : RT_SHADE_WAVES)) void k_shade(DevScene sc, PathState in, PathState out, Ctl* ctl, uint32_t it_abs,
-                                               uint32_t max_depth, uint32_t* queue_out, double* lfx, double* lfy,
-                                               double* lfz, DevStats* stats) {
+                                               uint32_t max_depth, uint32_t* queue_out, f64_t* lfx, f64_t* lfy,
+                                               f64_t* lfz, DevStats* stats) {
     const uint32_t it = it_abs % kRing, itn = (it_abs + 1) % kRing;
     const uint32_t n_active = ctl->n_active[it];
     // whole block past the end: nothing to do (block-uniform exit: the block barriers below stay well-formed)
@@ -855,8 +838,8 @@ __global__ __launch_bounds__(256, FEAT <= RT_SHADE4_MAXFEAT ? 4 : (feat_three_wa
 // are always counted (rt_stats.tail_*), so that the traversal kernel's own share is known exactly.
 template <int FEAT, bool COUNT>
 __global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathState buf1, Ctl* ctl,
-                                             uint32_t it_abs, uint32_t max_depth, double* lfx, double* lfy,
-                                             double* lfz, DevStats* stats) {
+                                             uint32_t it_abs, uint32_t max_depth, f64_t* lfx, f64_t* lfy,
+                                             f64_t* lfz, DevStats* stats) {
     __shared__ int2 lds_stack[kLdsStack * 256];
     __shared__ uint32_t s_job[4][192];  // per wave: slot of the path | ray kind << 30
     __shared__ int2 s_res[4][192];      // per wave: {prim, leaf slot} found for job j
@@ -981,6 +964,7 @@ __global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathS
     }
 }
 
+#ifndef RT_F32  // the film is f64 in both modes: compiled once
 // ------------------------------------------------------------------- resolve
 // util::increment_color order: each pixel's samples are added one by one, in sample order.
 __global__ __launch_bounds__(256) void k_resolve(const double* __restrict__ lfx, const double* __restrict__ lfy,
@@ -1017,5 +1001,7 @@ __global__ __launch_bounds__(256) void k_tonemap(const double* __restrict__ rgb_
         out[i * 3 + c] = (uint8_t)(v != v ? 0.0 : (v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v)));
     }
 }
+
+#endif
 
 }  // namespace rtd

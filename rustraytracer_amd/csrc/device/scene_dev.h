@@ -4,7 +4,10 @@
 
 #include "../../../include/rt_abi.h"
 
-namespace rtd {
+// The types of this header live in `rtc` (no functions there, so argument-dependent lookup adds nothing): they are
+// shared by the f64 kernels (namespace rtd) and the f32 fast-mode kernels generated from the same sources
+// (namespace rtd32, tools/make_f32_sources.py); both namespaces import them with a using-directive.
+namespace rtc {
 
 // BVH4 node, 128 B = exactly one L2 line / HBM burst pair: the four children's AABBs (f32, rounded
 // OUTWARD from the f64 primitive boxes, stored per axis so a lane reads them with eight 16-B loads)
@@ -85,6 +88,11 @@ struct DevScene {
     uint32_t n_prims, n_lights, n_nodes, mesh_has_uv;  // mesh_has_uv: any mesh carries uvs
     uint32_t simple_others, pad_so;                   // no sphere and no transformed rect in the scene
     DevEnv env;
+    // RT_PRECISION_F32 only (made by the first fast-mode render of the scene): binary32 copies of leaf_tri /
+    // leaf_nrm, 9 floats per slot.  A sphere / rect slot holds v[0..4] as floats and its {kind, transform} word
+    // as the bit patterns of floats 5 and 6.
+    const float* leaf_tri32;
+    const float* leaf_nrm32;
 };
 
 // ----------------------------------------------------------------- path state
@@ -129,4 +137,50 @@ struct DevStats {  // one shard = two 64-B lines; kStatShards shards, summed by 
 };
 constexpr int kStatShards = 64;
 
-}  // namespace rtd
+// ------------------------------------------------------------ kernel control blocks (kernels.hip)
+constexpr uint32_t kRing = 512;  // per-iteration counters live in a ring indexed by it % kRing
+
+struct Ctl {
+    uint32_t n_active[kRing];
+    uint32_t n_rays[kRing];
+    uint32_t head[kRing];
+    // written by k_plan for the k_generate that follows it
+    uint32_t gen_count, gen_first, gen_slot, gen_q;
+};
+
+// The batch being rendered, shared by both lanes.
+struct BatchCtl {
+    unsigned long long next;  // next camera sample (path index inside the batch) to generate
+};
+
+// Host-visible copy of the per-iteration counters (pinned, mapped memory).  k_trace(it) publishes
+// {n_active[it], n_rays[it]} when it STARTS; the host sizes the grids of iteration it+2 from it
+// (counts never grow) and stops launching once a published n_active is zero -- no stream sync.
+struct MirrorEntry {
+    uint32_t n_active, n_rays, seq, remaining;  // remaining: camera samples of the batch not yet generated (saturated)
+};
+
+struct ChunkDesc {
+    uint32_t n_pixels;     // pixels in this batch (PB)
+    uint32_t n_samples;    // samples per pixel in this batch
+    uint32_t pixel_base;   // offset into pix_list
+    uint32_t sample_base;  // first sample index
+    uint32_t width, height;
+    uint64_t seed;
+};
+
+struct TraceTune {
+    int refill_lanes;  // refill when at least this many lanes are idle (<= 64)
+    int node_bias;     // a node step runs when lanes_at_nodes * node_bias >= lanes_at_leaves * 4 (4 = plain majority)
+    int unused;
+    int reserve;       // queue entries a wave reserves per atomic (refills are served from the reservation)
+};
+
+}  // namespace rtc
+
+namespace rtd {
+using namespace rtc;
+}
+namespace rtd32 {
+using namespace rtc;
+}

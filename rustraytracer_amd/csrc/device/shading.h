@@ -68,7 +68,7 @@ RTD D3 hdr_value(const rt_texture& t, double u, double v) {
     x = x % width;
     y = y % height;
     const uint32_t q = reinterpret_cast<const uint32_t*>(t.rgbe)[(size_t)y * width + x];  // c0 | c1<<8 | c2<<16 | e<<24
-    const double sc = dm_from_bits((uint64_t)(1023 + (int)(q >> 24) - 128) << 52);       // 2^(e-128), exact
+    const f64_t sc = dm_from_bits((uint64_t)(1023 + (int)(q >> 24) - 128) << 52);        // 2^(e-128), exact
     return d3(((double)(q & 0xffu) + 0.5) * sc / 256.0, ((double)((q >> 8) & 0xffu) + 0.5) * sc / 256.0,
               ((double)((q >> 16) & 0xffu) + 0.5) * sc / 256.0);
 }
@@ -706,7 +706,7 @@ RTD double prim_pdf(const DevScene& sc, const rt_primitive& pr, D3 rec_p, D3 dir
 }
 // ------------------------------------------------------ Light::Infinite
 // distribution.rs:152-166 find_interval over cdf[0..size) with pred = cdf[i] <= u
-RTD uint32_t find_interval(const double* __restrict__ cdf, uint32_t size, double u) {
+RTD uint32_t find_interval(const f64_t* __restrict__ cdf, uint32_t size, double u) {
     uint32_t first = 0, len = size;
     while (len > 0) {
         const uint32_t half = len >> 1, middle = first + half;
@@ -722,7 +722,7 @@ RTD uint32_t find_interval(const double* __restrict__ cdf, uint32_t size, double
     return sat_u32(clampd(x, 0.0, (double)(size - 2)));
 }
 // distribution.rs:64-78 sample_continuous
-RTD void dist1d_sample(const double* __restrict__ func, const double* __restrict__ cdf, uint32_t n, double func_int,
+RTD void dist1d_sample(const f64_t* __restrict__ func, const f64_t* __restrict__ cdf, uint32_t n, double func_int,
                        double u, double& x, double& pdf, uint32_t& offset) {
     offset = find_interval(cdf, n + 1, u);
     double du = u - cdf[offset];

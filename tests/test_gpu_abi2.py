@@ -163,3 +163,75 @@ def test_primitive_count_limit():
     assert b"2^27" in L.rt_last_error()
     L.rt_scene_destroy(h)
     ctx.close()
+
+
+def _rmse(a, b, drop_top=0.0):
+    d = ((a - b) ** 2).sum(axis=-1).reshape(-1)
+    if drop_top > 0.0:
+        k = int(np.ceil(d.size * drop_top))
+        d = np.sort(d)[:d.size - k]
+    return float(np.sqrt(d.mean() / 3.0))
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "cornell_statue_plastic", "dragon_metal", "two_dragons", "hdr_glass"])
+def test_f32_fast_mode_is_reported_not_gated(gpu_ctx, name):
+    """RT_PRECISION_F32: the same kernels in binary32.  Same sample counts and camera samples; paths diverge from the
+    f64 ones after a few bounces, so the per-pixel difference at low spp is Monte-Carlo noise (SURVEY.md 8d expects
+    1e-3..1e-2 and asks for it to be REPORTED with and without the top 0.01 % pixels).  What is asserted here is only
+    that the fast mode is a faithful estimator of the same image: image means within 2 %, and a per-pixel RMSE that
+    stays at the Monte-Carlo noise level of the sample count (a few 1e-3 at 256 spp)."""
+    make = {"cornell_box": lambda: rr.cornell_box(),
+            "cornell_statue_plastic": lambda: rr.cornell_box_statue(mesh_faces=8000, variant=3),
+            "dragon_metal": lambda: rr.plastic_dragon(mesh_faces=8000, variant=1),
+            "two_dragons": lambda: rr.two_dragons(mesh_faces=6000, variant=0),
+            "hdr_glass": lambda: rr.material_hdr(3, mesh_faces=4000)}[name]
+    sc = make()
+    gs = gpu_ctx.upload(sc)
+    out = {}
+    for spp in (16, 256):
+        r64, n64, s64 = gpu_ctx.render(gs, sc.camera, rr.make_cfg(64, 64, spp, seed=7))
+        r32, n32, s32 = gpu_ctx.render(gs, sc.camera, rr.make_cfg(64, 64, spp, seed=7, precision=F.RT_PRECISION_F32))
+        assert np.array_equal(n32, n64) and s32.paths == s64.paths
+        i64, i32 = r64 / n64[..., None], r32 / n32[..., None]
+        ok = np.isfinite(i64).all(axis=-1) & np.isfinite(i32).all(axis=-1)
+        assert ok.mean() > 0.999
+        i64, i32 = np.where(ok[..., None], i64, 0.0), np.where(ok[..., None], i32, 0.0)
+        m64, m32 = np.clip(i64, 0, 10).mean(), np.clip(i32, 0, 10).mean()
+        out[spp] = (_rmse(np.clip(i64, 0, 10), np.clip(i32, 0, 10)), _rmse(np.clip(i64, 0, 10), np.clip(i32, 0, 10), 1e-4), m64, m32)
+        assert abs(s32.rays / s64.rays - 1.0) < 0.02  # the same amount of work
+    print(f"\n[f32 vs f64] {name}: RMSE @16 spp {out[16][0]:.4g} (without top 0.01 %: {out[16][1]:.4g}), "
+          f"@256 spp {out[256][0]:.4g} ({out[256][1]:.4g}); image mean f64 {out[256][2]:.5g} f32 {out[256][3]:.5g}")
+    assert abs(out[256][3] / out[256][2] - 1.0) < 0.02
+    assert out[256][0] < 5e-3
+    gs.close()
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "cornell_box_spheres", "sphere_roughness", "statue", "two_dragons"])
+def test_f32_traversal_finds_the_same_primitives(gpu_ctx, monkeypatch, name):
+    """Kernel-level check of the fast mode: RT_INTERSECT_F32=1 runs the binary32 traversal behind
+    rt_intersect_batch.  On rays whose f64 hit is not within rounding distance of another primitive the two modes
+    must name the same primitive; a handful of edge / silhouette rays may differ.  (This is the test that found a
+    compiler problem in the binary32 instance: all yz rects were missed.)"""
+    make = {"cornell_box": lambda: rr.cornell_box(), "cornell_box_spheres": lambda: rr.cornell_box_spheres(),
+            "sphere_roughness": lambda: rr.sphere_roughness(),
+            "statue": lambda: rr.cornell_box_statue(mesh_faces=20000, variant=0),
+            "two_dragons": lambda: rr.two_dragons(mesh_faces=20000)}[name]
+    sc = make()
+    gs = gpu_ctx.upload(sc)
+    rng = np.random.default_rng(11)
+    n = 200000
+    lo, hi = (5.0, 550.0) if name in ("cornell_box", "cornell_box_spheres", "statue") else (-9.0, 9.0)
+    o = rng.uniform(lo, hi, size=(n, 3)).astype(np.float32).astype(np.float64)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1)[:, None]).astype(np.float32).astype(np.float64)
+    monkeypatch.delenv("RT_INTERSECT_F32", raising=False)
+    t64, p64 = gpu_ctx.intersect_batch(gs, o, d, F.RT_SMALL)
+    monkeypatch.setenv("RT_INTERSECT_F32", "1")
+    t32, p32 = gpu_ctx.intersect_batch(gs, o, d, F.RT_SMALL)
+    monkeypatch.delenv("RT_INTERSECT_F32", raising=False)
+    gs.close()
+    assert (p64 >= 0).mean() > 0.3
+    same = p64 == p32
+    assert same.mean() > 0.999, (name, float(same.mean()))
+    hit = same & (p64 >= 0)
+    assert np.all(np.abs(t32[hit] - t64[hit]) <= 2e-4 * np.maximum(1.0, np.abs(t64[hit])))

@@ -23,7 +23,7 @@ for p in sorted(glob.glob(os.path.join(root, "sq1", "*", "*kernel_trace.csv"))):
         dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
 res = {}
 for k in out:
-    if not k.startswith("rtd::"):
+    if not (k.startswith("rtd::") or k.startswith("rtd32::")):
         continue
     d = dict(out[k])
     d["calls"] = calls.get(k, 0)
