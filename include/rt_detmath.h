@@ -132,6 +132,30 @@ RT_HD double dm_cos(double x) {
     }
 }
 
+/* sin and cos of one argument with one argument reduction.  Bit for bit the pair (dm_sin(x), dm_cos(x)): the same
+ * kernels on the same reduced argument, only the duplicated reduction is gone.                                */
+RT_HD void dm_sincos(double x, double* s, double* c) {
+    uint32_t ix = dm_hi(x) & 0x7fffffffu;
+    if (ix <= 0x3fe921fbu) {
+        *s = dm_ksin(x, 0.0, 0);
+        *c = dm_kcos(x, 0.0);
+        return;
+    }
+    if (ix >= 0x7ff00000u) {
+        *s = *c = x - x;
+        return;
+    }
+    double y0, y1;
+    int n = dm_rem_pio2(x, &y0, &y1);
+    double ks = dm_ksin(y0, y1, 1), kc = dm_kcos(y0, y1);
+    switch (n) {
+        case 0: *s = ks; *c = kc; break;
+        case 1: *s = kc; *c = -ks; break;
+        case 2: *s = -ks; *c = -kc; break;
+        default: *s = -kc; *c = ks; break;
+    }
+}
+
 /* ---- atan / atan2 --------------------------------------------------------- */
 RT_HD double dm_atan(double x) {
     const double atanhi0 = 4.63647609000806093515e-01, atanhi1 = 7.85398163397448278999e-01,

@@ -34,6 +34,10 @@ RTD double dm_atan2(double y, double x) { return ::atan2f(y, x); }
 RTD double dm_acos(double x) { return ::acosf(x); }
 RTD double dm_log(double x) { return ::logf(x); }
 RTD double dm_sqrt(double x) { return __builtin_sqrt(x); }
+struct SinCos {
+    double s, c;
+};
+RTD SinCos sincos2(double x) { return SinCos{::sinf(x), ::cosf(x)}; }
 #else
 // The elementary functions are called from dozens of sites of the shading code; inlined everywhere they blew
 // the shading kernels up to 170-290 KB of code against a 64 KB instruction cache.  One out-of-line copy each:
@@ -43,11 +47,28 @@ RTDN double ni_cos(double x) { return dm_cos(x); }
 RTDN double ni_atan2(double y, double x) { return dm_atan2(y, x); }
 RTDN double ni_acos(double x) { return dm_acos(x); }
 RTDN double ni_log(double x) { return dm_log(x); }
+struct SinCos {
+    double s, c;
+};
+RTDN SinCos sincos2(double x) {  // == {dm_sin(x), dm_cos(x)} bit for bit, with one argument reduction (rt_detmath.h)
+    SinCos r;
+    dm_sincos(x, &r.s, &r.c);
+    return r;
+}
 #define dm_sin ni_sin
 #define dm_cos ni_cos
 #define dm_atan2 ni_atan2
 #define dm_acos ni_acos
 #define dm_log ni_log
+#else
+struct SinCos {
+    double s, c;
+};
+RTD SinCos sincos2(double x) {
+    SinCos r;
+    dm_sincos(x, &r.s, &r.c);
+    return r;
+}
 #endif
 #endif
 

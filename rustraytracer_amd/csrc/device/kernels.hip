@@ -504,10 +504,24 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool va
                     const int32_t li = sc.prims[pp].light_index;
                     if (li >= 0 && (uint32_t)li == light_idx) {
                         const D3 pd = ld3(in.pdx, in.pdy, in.pdz, slot);
-                        HitRec nh;
-                        if (prim_intersects(sc, pp, a.o, pd, kSmall, kInf, nh)) {
-                            const D3 col = light_l(sc.lights[li], nh.n, -pd);  // new_record.le(-wi)
-                            if (!is_black(col)) ld = ld + q_in;
+                        const rt_primitive& lpr = sc.prims[pp];
+                        if (lpr.kind >= RT_PRIM_XY_RECT && lpr.xform_index < 0) {
+                            // axis-aligned rect emitter: the record's normal faces the ray (set_front), so
+                            // dot(n, -wi) = |wi's component along the rect's axis| and Light::l sees the colour
+                            // unless that component is zero -- no need to build the record
+                            double t, ra, rb;
+                            D3 to, td;
+                            if (rect_core(sc, lpr, a.o, pd, kSmall, kInf, t, ra, rb, to, td)) {
+                                const rt_light& lt2 = sc.lights[li];
+                                const bool lit = lt2.two_sided || absd(rect_axis_comp(lpr.kind, pd)) > 0.0;
+                                if (lit && !is_black(d3(lt2.color[0], lt2.color[1], lt2.color[2]))) ld = ld + q_in;
+                            }
+                        } else {
+                            HitRec nh;
+                            if (prim_intersects(sc, pp, a.o, pd, kSmall, kInf, nh)) {
+                                const D3 col = light_l(sc.lights[li], nh.n, -pd);  // new_record.le(-wi)
+                                if (!is_black(col)) ld = ld + q_in;
+                            }
                         }
                     }
                 }

@@ -46,8 +46,9 @@ RTD D3 rand_cosine_dir(double r1, double r2) {
         r = u2;
         theta = kPi / 2.0 - kPi / 4.0 * (u1 / u2);
     }
-    double x = r * dm_cos(theta);
-    double y = r * dm_sin(theta);
+    const SinCos sc_ = sincos2(theta);
+    double x = r * sc_.c;
+    double y = r * sc_.s;
     double z = dm_sqrt(rmax(0.0, 1.0 - x * x - y * y));
     return d3(x, y, z);
 }
@@ -197,8 +198,9 @@ RTD void tr_sample_11(double cos_theta, double u1, double u2, double& sx, double
     if (cos_theta > 0.9999) {
         double r = dm_sqrt(u1 / (1.0 - u1));
         double phi = 2.0 * kPi * u2;
-        sx = r * dm_cos(phi);
-        sy = r * dm_sin(phi);
+        const SinCos sc_ = sincos2(phi);
+        sx = r * sc_.c;
+        sy = r * sc_.s;
         return;
     }
     double sin_t = rmax(0.0, dm_sqrt(1.0 - cos_theta * cos_theta));
@@ -659,7 +661,8 @@ RTD D3 uniform_sample_sphere(double u0, double u1) {  // util.rs:51-56
     double z = 1.0 - 2.0 * u0;
     double r = dm_sqrt(rmax(0.0, 1.0 - z * z));
     double phi = 2.0 * kPi * u1;
-    return d3(r * dm_cos(phi), r * dm_sin(phi), z);
+    const SinCos sc_ = sincos2(phi);
+    return d3(r * sc_.c, r * sc_.s, z);
 }
 RTD void sample_area(const DevScene& sc, const rt_primitive& pr, double u0, double u1, D3& p, D3& n, double& pdf) {
     if (pr.kind == RT_PRIM_SPHERE) {
@@ -699,6 +702,16 @@ RTD D3 light_l(const rt_light& lt, D3 n, D3 w) {  // light.rs:475-496
     return black();
 }
 RTD double prim_pdf(const DevScene& sc, const rt_primitive& pr, D3 rec_p, D3 dir) {  // primitive.rs:462-473
+    if (pr.kind >= RT_PRIM_XY_RECT && pr.xform_index < 0) {
+        // the usual emitter, an axis-aligned rect: intersects_obj's record is only read for its point and for
+        // |dot(n, -dir)|; n is a signed unit axis (rect_record), so the dot product is dir's component along that
+        // axis, exactly -- the same value without building the record (two normalisations, two uv divisions)
+        double t, a, b;
+        D3 to, td;
+        if (!rect_core(sc, pr, rec_p, dir, 0.0, kInf, t, a, b, to, td)) return 0.0;
+        const D3 dist = rec_p - (to + td * t);
+        return norm2(dist) / (prim_area(sc, pr) * absd(rect_axis_comp(pr.kind, dir)));
+    }
     HitRec nh;
     if (!intersects_obj(sc, pr, rec_p, dir, 0.0, kInf, nh)) return 0.0;
     D3 dist = rec_p - nh.p;
@@ -783,8 +796,8 @@ RTDN void infinite_sample_li(const DevScene& sc, const rt_light& lt, D3 p, doubl
         return;
     }
     const double theta = uv1 * kPi, phi = uv0 * 2.0 * kPi;
-    const double cos_theta = dm_cos(theta), sin_theta = dm_sin(theta);
-    const double cos_phi = dm_cos(phi), sin_phi = dm_sin(phi);
+    const SinCos sct = sincos2(theta), scp = sincos2(phi);
+    const double cos_theta = sct.c, sin_theta = sct.s, cos_phi = scp.c, sin_phi = scp.s;
     const D3 v = d3(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta);
     const D3 wiv = light_to_world(sc, lt, v);
     pdf = map_pdf / (2.0 * kPi * kPi * sin_theta);
