@@ -8,6 +8,7 @@ import numpy as np
 
 import rustraytracer_amd as rr
 from tests import oracle_ffi as O
+from tests.test_gpu_arms import emitter_scene
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -20,6 +21,9 @@ makers = [
     ("two_dragons", lambda f, v: rr.two_dragons(mesh_faces=f, variant=v % 2)),
     ("sphere_roughness", lambda f, v: rr.sphere_roughness()),
     ("material_hdr", lambda f, v: rr.material_hdr(v % 4, mesh_faces=f)),
+    # round 2: triangle / sphere emitters, a uv-mapped checkered mesh, a mesh without normals (tests/test_gpu_arms.py)
+    ("emitters", lambda f, v: emitter_scene(bool(v & 1), sphere_light=bool(v & 2) or not (v & 4), tri_lights=bool(v & 4) or not (v & 2),
+                                            two_sided=bool(v & 1))),
 ]
 bad = 0
 for case in range(n_cases):
