@@ -357,6 +357,15 @@ int rt_render_device(rt_context* ctx, rt_scene* s, const rt_camera* cam, const r
 /* Kernel-level parity entry: closest hit of BvhNode::intersects
  * (hittable.rs:591-634) for n host rays.                                      */
 int rt_intersect_batch(rt_context* ctx, rt_scene* s, const rt_ray* rays, uint64_t n, rt_hit* hits);
+/* Same query through other code paths (kernel-level tests):
+ *   RT_INTERSECT_F32        the binary32 traversal of the fast mode
+ *   RT_INTERSECT_WAVEFRONT  the render's own traversal kernel (persistent waves, queue
+ *                           reservations, refill, while-while scheduling) instead of the
+ *                           run-to-completion loop; rays must use tmin = RT_SMALL, tmax =
+ *                           RT_INFINITY (what extension and probe rays use)             */
+#define RT_INTERSECT_F32 1u
+#define RT_INTERSECT_WAVEFRONT 2u
+int rt_intersect_batch_ex(rt_context* ctx, rt_scene* s, const rt_ray* rays, uint64_t n, rt_hit* hits, uint32_t flags);
 
 /* Next-row f1: film resolve -> ACES approx -> gamma -> 8-bit
  * (util.rs:400-408, 441-471).  rgb8 = W*H*3 bytes, host pointers.             */

@@ -139,7 +139,8 @@ class Context:
                                         C.c_void_p(d_n_ptr), C.c_void_p(stream or 0), C.byref(st)))
         return st
 
-    def intersect_batch(self, gscene, origins, dirs, tmin, tmax=F.RT_INFINITY):
+    def intersect_batch(self, gscene, origins, dirs, tmin, tmax=F.RT_INFINITY, flags=0):
+        """rt_intersect_batch_ex; flags: F.RT_INTERSECT_F32 | F.RT_INTERSECT_WAVEFRONT"""
         origins = np.ascontiguousarray(origins, dtype=np.float64)
         dirs = np.ascontiguousarray(dirs, dtype=np.float64)
         n = origins.shape[0]
@@ -150,7 +151,7 @@ class Context:
         ra[:, 6] = tmin
         ra[:, 7] = tmax
         hits = (F.rt_hit * n)()
-        _check(F.lib().rt_intersect_batch(self._h, gscene._h, rays, n, hits))
+        _check(F.lib().rt_intersect_batch_ex(self._h, gscene._h, rays, n, hits, flags))
         ha = np.frombuffer(hits, dtype=np.dtype([("t", "<f8"), ("prim", "<i4"), ("r", "<u4")]))
         self.last_intersect_cost = ha["r"].copy()  # nodes | tris << 8 | others << 16 per ray (saturating bytes)
         return ha["t"].copy(), ha["prim"].copy()

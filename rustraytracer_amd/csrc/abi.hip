@@ -1416,11 +1416,79 @@ int rt_render(rt_context* c, rt_scene* s, const rt_camera* cam, const rt_render_
     return rc;
 }
 
+// rt_intersect_batch_ex with RT_INTERSECT_WAVEFRONT: the caller's rays go through the RENDER's traversal kernel
+// (k_trace: persistent waves, queue reservations, refill, while-while scheduling, deferred write-back) instead of the
+// run-to-completion loop of k_intersect_batch -- a kernel-level parity entry for exactly the code the films depend on.
+__global__ __launch_bounds__(256) void k_wf_setup(const rt_ray* __restrict__ rays, uint32_t n, PathState st, uint32_t* queue,
+                                                  Ctl* ctl, int f32) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        ctl->n_rays[0] = n;
+        ctl->n_active[0] = n;
+        ctl->head[0] = 0;
+    }
+    if (i >= n) return;
+    const rt_ray r = rays[i];
+    // (the fast mode keeps binary32 values in the low half of each state slot, kernels.hip: ld3 / st3)
+    auto put = [&](double* a, double v) {
+        if (f32)
+            reinterpret_cast<float*>(a)[2u * i] = (float)v;
+        else
+            a[i] = v;
+    };
+    put(st.ox, r.origin[0]); put(st.oy, r.origin[1]); put(st.oz, r.origin[2]);
+    // the three ray kinds of the render read their direction from different fields: spread the rays over two of them
+    // (an extension ray and a probe ray are both traced on [SMALL, inf) -- a shadow ray is not a free-form ray)
+    if (i & 1u) {
+        put(st.pdx, r.dir[0]); put(st.pdy, r.dir[1]); put(st.pdz, r.dir[2]);
+        queue[i] = i | (kRayProbe << 30);
+    } else {
+        put(st.dx, r.dir[0]); put(st.dy, r.dir[1]); put(st.dz, r.dir[2]);
+        queue[i] = i | (kRayExt << 30);
+    }
+    st.hit_prim[i] = -2;
+    st.pr_prim[i] = -2;
+}
+__global__ __launch_bounds__(256) void k_wf_collect(DevScene sc, const rt_ray* __restrict__ rays, uint32_t n, PathState st,
+                                                    rt_hit* hits) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const rt_ray r = rays[i];
+    const int32_t prim = (i & 1u) ? st.pr_prim[i] : st.hit_prim[i];
+    rt_hit h;
+    h.prim = prim;
+    h.t = kInf;
+    h.reserved = 0;
+    if (prim >= 0) {  // the winner's own test gives t (the same arithmetic as the traversal's)
+        HitRec rec;
+        if (prim_intersects(sc, prim, d3(r.origin[0], r.origin[1], r.origin[2]), d3(r.dir[0], r.dir[1], r.dir[2]), r.tmin, r.tmax, rec))
+            h.t = rec.t;
+    }
+    hits[i] = h;
+}
+
 int rt_intersect_batch(rt_context* c, rt_scene* s, const rt_ray* rays, uint64_t n, rt_hit* hits) {
+    return rt_intersect_batch_ex(c, s, rays, n, hits, 0u);
+}
+
+int rt_intersect_batch_ex(rt_context* c, rt_scene* s, const rt_ray* rays, uint64_t n, rt_hit* hits, uint32_t flags) {
     if (!c || !s || (n && (!rays || !hits))) return fail(RT_ERR_INVALID_ARG, "rt_intersect_batch: null argument");
     if (!s->committed) return fail(RT_ERR_STATE, "rt_intersect_batch: scene is not committed");
+    if (flags & ~(uint32_t)(RT_INTERSECT_F32 | RT_INTERSECT_WAVEFRONT)) return fail(RT_ERR_INVALID_ARG, "rt_intersect_batch_ex: unknown flags 0x%x", flags);
     if (n == 0) return RT_OK;
+    const bool f32 = (flags & RT_INTERSECT_F32) != 0, wavefront = (flags & RT_INTERSECT_WAVEFRONT) != 0;
+    if (wavefront) {
+        if (n > (1u << 26)) return fail(RT_ERR_UNSUPPORTED, "rt_intersect_batch_ex: more than 2^26 rays in wavefront mode");
+        for (uint64_t i = 0; i < n; i++)
+            if (rays[i].tmin != RT_SMALL || rays[i].tmax != RT_INFINITY)
+                return fail(RT_ERR_UNSUPPORTED, "rt_intersect_batch_ex: wavefront mode traces on [RT_SMALL, RT_INFINITY) only (ray %llu)",
+                            (unsigned long long)i);
+    }
     HIP_TRY(hipSetDevice(c->device));
+    if (f32) {
+        const int frc = ensure_f32_leaves(s, c->stream);
+        if (frc != RT_OK) return frc;
+    }
     rt_ray* d_rays = nullptr;
     rt_hit* d_hits = nullptr;
     HIP_TRY(hipMalloc((void**)&d_rays, n * sizeof(rt_ray)));
@@ -1431,17 +1499,34 @@ int rt_intersect_batch(rt_context* c, rt_scene* s, const rt_ray* rays, uint64_t 
     }
     int rc = RT_OK;
     e = hipMemcpyAsync(d_rays, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) {
-        // (debug / tests: RT_INTERSECT_F32=1 runs the fast-mode traversal on the same rays)
-        if (getenv("RT_INTERSECT_F32") && ensure_f32_leaves(s, c->stream) == RT_OK)
+    if (e == hipSuccess && wavefront) {
+        Lane& ln = c->lanes[0];
+        rc = ensure_lane_capacity(c, ln, (uint32_t)((n + 63) & ~(uint64_t)63));
+        if (rc == RT_OK) {
+            const unsigned blocks = (unsigned)((n + 255) / 256);
+            int occ = 0;
+            const TraceKernel tk = trace_kernel(false, s->dev.simple_others != 0, f32);
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, tk, 256, 0);
+            const unsigned tblocks = std::max(1u, std::min(blocks, (unsigned)(c->num_cus * std::max(1, occ))));
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_wf_setup, dim3(blocks), dim3(256), 0, c->stream, d_rays, (uint32_t)n, ln.st[0], ln.queue[0], ln.ctl, f32 ? 1 : 0);
+                hipLaunchKernelGGL(tk, dim3(tblocks), dim3(256), 0, c->stream, s->dev, ln.st[0], ln.queue[0], ln.ctl, 0u, c->stats,
+                                   c->tune, (MirrorEntry*)nullptr, 0u, c->batch, 0ull);
+                hipLaunchKernelGGL(k_wf_collect, dim3(blocks), dim3(256), 0, c->stream, s->dev, d_rays, (uint32_t)n, ln.st[0], d_hits);
+                e = hipGetLastError();
+            }
+        }
+    } else if (e == hipSuccess) {
+        if (f32)
             hipLaunchKernelGGL(rtd32::k_intersect_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, s->dev, d_rays, n, d_hits);
         else
             hipLaunchKernelGGL(rtd::k_intersect_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, s->dev, d_rays, n, d_hits);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(hits, d_hits, n * sizeof(rt_hit), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) rc = fail(RT_ERR_HIP, "rt_intersect_batch: %s", hipGetErrorString(e));
+    if (rc == RT_OK && e == hipSuccess) e = hipMemcpyAsync(hits, d_hits, n * sizeof(rt_hit), hipMemcpyDeviceToHost, c->stream);
+    if (rc == RT_OK && e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (rc == RT_OK && e != hipSuccess) rc = fail(RT_ERR_HIP, "rt_intersect_batch: %s", hipGetErrorString(e));
+    (void)hipDeviceSynchronize();
     (void)hipFree(d_rays);
     (void)hipFree(d_hits);
     return rc;

@@ -366,6 +366,31 @@ def test_full_size_scenes_bit_identical(gpu_ctx, case):
     gs.close()
 
 
+def test_c4_headline_scene_full_size_bit_identical(gpu_ctx):
+    """The bench's own scene -- two_dragons with 2 x 871 414 triangles at the 16:9 aspect -- against the oracle at a
+    quarter of the image size, in one shot and as a 3-way tile split ("has never been through a
+    driver-run test")."""
+    sc = rr.two_dragons(1920 / 1080, mesh_faces=871414)
+    assert sc.desc.contents.n_prims == 2 + 2 * 871414
+    osc = O.OracleScene(sc)
+    gs = gpu_ctx.upload(sc)
+    cfg = rr.make_cfg(480, 270, 8, seed=0)
+    ro, no, so = osc.render(sc.camera, cfg, O.ORDERED, threads=16)
+    rg, ng, sg = gpu_ctx.render(gs, sc.camera, cfg)
+    assert np.array_equal(ng, no)
+    assert (sg.rays_extension, sg.rays_shadow, sg.rays_probe, sg.vertices_shaded) == \
+           (so.rays_extension, so.rays_shadow, so.rays_probe, so.vertices_shaded)
+    finite = np.isfinite(ro)
+    assert np.array_equal(np.isfinite(rg), finite) and np.array_equal(rg[finite], ro[finite])
+    acc, nacc = np.zeros_like(rg), np.zeros_like(ng)
+    for r in range(3):
+        a, b, _ = gpu_ctx.render(gs, sc.camera, rr.make_cfg(480, 270, 8, seed=0, tile_rank=r, tile_world=3))
+        acc += a
+        nacc += b
+    assert np.array_equal(nacc, no) and np.array_equal(acc[finite], ro[finite])
+    gs.close()
+
+
 # ------------------------------------------------------------------ next-row f3: BVH built on the GPU
 def _same_hits(gpu_ctx, sc, lo, hi, n_rays=100000, seed=7):
     """device-built BVH == host-built BVH == oracle, prim index and t bit for bit"""
