@@ -10,8 +10,8 @@ Workload (every N): BASELINE.json's metric config, configs[3] = C4 -- two_dragon
 dragons (glass + metal, 2 x procedural P-871k in place of the missing dragon.obj), 1920x1080 @
 1024 spp, max_depth 25, seed 0.  It fits one GPU (the scene is 0.5 GB; path state + film staging
 ~40 GB of the 288 GB).
-N > 1: STRONG scaling -- the same image, its 16x16 tiles interleaved over the ranks (tile k -> rank
-k % N, rt_render_cfg.tile_rank / tile_world), every rank renders only its tiles and the own-tile
+N > 1: STRONG scaling -- the same image, its 16x16 tiles interleaved over the ranks (tile (tx, ty) -> rank
+rt_tile_owner(tx, ty, N), rt_render_cfg.tile_rank / tile_world), every rank renders only its tiles and the own-tile
 pixels are packed and gathered to rank 0 over RCCL/xGMI (rustraytracer_amd/dist.py); the gather
 time is reported separately (`gather_ms_per_step`) and is inside the timed region.
 

@@ -224,8 +224,9 @@ typedef struct rt_render_cfg {
     uint64_t seed;
     uint32_t x0, y0, x1, y1;  /* pixel window [x0,x1) x [y0,y1); 0,0,0,0 = all */
     uint32_t tile_size;       /* 16 (consts.rs:10); 0 = 16                     */
-    uint32_t tile_rank;       /* this caller renders tiles k with              */
-    uint32_t tile_world;      /*   k % tile_world == tile_rank; 0 = 1          */
+    uint32_t tile_rank;       /* this caller renders the tiles (tx, ty) with   */
+    uint32_t tile_world;      /*   rt_tile_owner(tx, ty, tile_world) ==
+                                   tile_rank (below); 0 = 1                    */
     uint32_t precision;       /* rt_precision                                  */
     uint32_t paths_in_flight; /* 0 = library default                           */
     uint32_t flags;           /* RT_RENDER_* below                             */
@@ -240,6 +241,31 @@ typedef struct rt_render_cfg {
      * kernel launches; once it reads non-zero the call drains the device and returns RT_ERR_CANCELLED.  */
     const volatile int32_t* cancel;
 } rt_render_cfg;
+
+/* Which of `world` callers owns tile (tx, ty) (tiles of tile_size x tile_size pixels, tx and ty counted from the
+ * image's upper left corner).  The reference hands tiles to its workers in row-major order (render.rs:49-71);
+ * "tile k -> k % world" would do the same here, but with a tile row that is a multiple of `world` long (1920 / 16 =
+ * 120 tiles for 2, 4, 8 GPUs) that deals whole tile COLUMNS to a rank, and the cost of a picture is not spread
+ * evenly over its columns (measured on two_dragons, 8 ranks: slowest rank 2.3 % above the mean).  So the owner is
+ * a rank-1 lattice instead: (tx + ty * s) % world, s = the integer nearest to world / golden ratio that is coprime
+ * to world -- every row and every column of tiles visits all ranks in turn.  Pixels do not
+ * depend on who renders them, so any rule gives the same film; this one is part of the interface because the
+ * gather (rustraytracer_amd/dist.py, a host's own) has to know it: rt_tile_owner() below exports it, the inline
+ * form is for code that does not link the library.                                                              */
+static inline uint32_t rtabi_tile_stride(uint32_t world) {
+    if (world <= 1) return 0;
+    uint32_t s = (uint32_t)(((uint64_t)world * 618034u + 500000u) / 1000000u);
+    if (s == 0) s = 1;
+    for (;; s++) {
+        uint32_t a = s, b = world;
+        while (b) { const uint32_t t = a % b; a = b; b = t; }
+        if (a == 1) return s % world;
+    }
+}
+static inline uint32_t rtabi_tile_owner(uint32_t tx, uint32_t ty, uint32_t world) {
+    if (world <= 1) return 0;
+    return (uint32_t)(((uint64_t)tx + (uint64_t)ty * rtabi_tile_stride(world)) % world);
+}
 
 #define RT_RENDER_COUNT_TRAVERSAL 1u /* fill the node/prim test counters       */
 #define RT_RENDER_ACCUMULATE 2u      /* add to the film passed in instead of
@@ -294,6 +320,9 @@ typedef struct rt_hit {
 
 typedef struct rt_context rt_context;
 typedef struct rt_scene rt_scene;
+
+/* = rtabi_tile_owner(tx, ty, world): the rank that renders tile (tx, ty) under rt_render_cfg.tile_world = world */
+uint32_t rt_tile_owner(uint32_t tx, uint32_t ty, uint32_t world);
 
 /* device_ids may be NULL with n_devices == 0 (device 0).  With n_devices > 1 the
  * context spans several GPUs of one node: scenes are

@@ -1626,8 +1626,8 @@ int oracle_render(const oracle_scene* s, const rt_camera* cam, const rt_render_c
         for (;;) {  // render.rs:49-71: workers claim 16x16 tiles in row-major order
             uint32_t k = next_tile.fetch_add(1);
             if (k >= tw * th) break;
-            if (k % world != rank) continue;
             uint32_t tx = k % tw, ty = k / tw;
+            if (rtabi_tile_owner(tx, ty, world) != rank) continue;  // include/rt_abi.h: the interface's tile -> rank rule
             for (uint32_t y = 0; y < ts; y++)
                 for (uint32_t x = 0; x < ts; x++) {
                     uint32_t px = tx * ts + x, py = ty * ts + y;

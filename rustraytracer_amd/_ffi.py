@@ -141,7 +141,7 @@ ABI_SYMBOLS = [
     "rt_context_create", "rt_context_destroy", "rt_scene_create", "rt_scene_set_meshes",
     "rt_scene_set_primitives", "rt_scene_set_transforms", "rt_scene_set_materials", "rt_scene_set_textures",
     "rt_scene_set_lights", "rt_scene_commit", "rt_scene_commit_ex", "rt_scene_destroy", "rt_scene_get_info", "rt_render",
-    "rt_render_device", "rt_intersect_batch", "rt_intersect_batch_ex", "rt_resolve_rgb8", "rt_last_error", "rt_abi_version",
+    "rt_render_device", "rt_intersect_batch", "rt_intersect_batch_ex", "rt_resolve_rgb8", "rt_last_error", "rt_abi_version", "rt_tile_owner",
 ]
 HOST_SYMBOLS = [
     "rrh_scene_build", "rrh_scene_destroy", "rrh_scene_desc", "rrh_scene_camera", "rrh_scene_name",
@@ -184,6 +184,8 @@ def lib():
     L.rt_render_device.argtypes = [vp, vp, C.POINTER(rt_camera), C.POINTER(rt_render_cfg), vp, vp, vp,
                                    C.POINTER(rt_stats)]
     L.rt_intersect_batch.argtypes = [vp, vp, C.POINTER(rt_ray), C.c_uint64, C.POINTER(rt_hit)]
+    L.rt_tile_owner.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+    L.rt_tile_owner.restype = C.c_uint32
     L.rt_intersect_batch_ex.argtypes = [vp, vp, C.POINTER(rt_ray), C.c_uint64, C.POINTER(rt_hit), C.c_uint32]
     L.rt_resolve_rgb8.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, vp]
     L.rrh_scene_build.argtypes = [C.c_char_p, C.c_double, C.c_uint64, C.c_char_p, C.c_int, C.POINTER(vp)]

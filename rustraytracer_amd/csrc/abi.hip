@@ -176,6 +176,7 @@ extern "C" {
 
 const char* rt_last_error(void) { return g_err; }
 int rt_abi_version(void) { return RT_ABI_VERSION; }
+uint32_t rt_tile_owner(uint32_t tx, uint32_t ty, uint32_t world) { return rtabi_tile_owner(tx, ty, world); }
 
 int rt_context_create(const int* device_ids, int n_devices, rt_context** out) {
     if (!out) return fail(RT_ERR_INVALID_ARG, "rt_context_create: out is null");
@@ -955,8 +956,9 @@ static size_t batch_max() {  // camera samples per batch (film staging: 24 B eac
 }
 #define kBatchMax (batch_max())
 
+// sub_rank / sub_world: device `sub_rank` of a several-device context takes every sub_world-th of the caller's tiles
 static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const rt_render_cfg* cfg, double* d_rgb,
-                       uint32_t* d_n, hipStream_t stream, rt_stats* stats) {
+                       uint32_t* d_n, hipStream_t stream, rt_stats* stats, uint32_t sub_rank = 0, uint32_t sub_world = 1) {
     const uint32_t W = cfg->width, H = cfg->height;
     const uint32_t spp = next_pow2(cfg->spp);
     uint32_t x0 = cfg->x0, y0 = cfg->y0, x1 = cfg->x1, y1 = cfg->y1;
@@ -966,12 +968,14 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
     const uint32_t ts = cfg->tile_size ? cfg->tile_size : 16;
     const uint32_t world = cfg->tile_world ? cfg->tile_world : 1;
     const uint32_t rank = cfg->tile_rank;
-    // owned pixels: tiles k (row-major) with k % world == rank; 16-wide rows inside a tile
+    // owned pixels: the tiles rt_tile_owner() gives this rank, in row-major order; 16-wide rows inside a tile
     std::vector<uint32_t> pix;
     const uint32_t tw = (W + ts - 1) / ts, th = (H + ts - 1) / ts;
+    uint32_t n_own = 0;
     for (uint32_t k = 0; k < tw * th; k++) {
-        if (k % world != rank) continue;
         const uint32_t tx = k % tw, ty = k / tw;
+        if (rtabi_tile_owner(tx, ty, world) != rank) continue;
+        if (n_own++ % sub_world != sub_rank) continue;
         for (uint32_t y = 0; y < ts; y++)
             for (uint32_t x = 0; x < ts; x++) {
                 const uint32_t px = tx * ts + x, py = ty * ts + y;
@@ -1250,11 +1254,15 @@ static int render_multi(rt_context* c, rt_scene* s, const rt_camera* cam, const 
     const size_t npix = (size_t)cfg->width * cfg->height;
     const uint32_t world = cfg->tile_world ? cfg->tile_world : 1;
     if ((uint64_t)world * (uint64_t)N > 0xffffffffull) return fail(RT_ERR_INVALID_ARG, "rt_render: tile_world too large");
+    // one caller (the usual case): the context's devices are the lattice's ranks; a caller that is itself one of
+    // several (tile_world > 1) keeps its own tiles and deals them to its devices in turn
     std::vector<rt_render_cfg> cfgs((size_t)N, *cfg);
-    for (int i = 0; i < N; i++) {
-        cfgs[i].tile_world = world * (uint32_t)N;
-        cfgs[i].tile_rank = cfg->tile_rank + world * (uint32_t)i;
-    }
+    const uint32_t sub_world = world > 1 ? (uint32_t)N : 1u;
+    if (world == 1)
+        for (int i = 0; i < N; i++) {
+            cfgs[i].tile_world = (uint32_t)N;
+            cfgs[i].tile_rank = (uint32_t)i;
+        }
     int rc = RT_OK;
     for (int i = 1; i < N; i++) {
         rt_context* p = c->peers[i - 1];
@@ -1284,10 +1292,11 @@ static int render_multi(rt_context* c, rt_scene* s, const rt_camera* cam, const 
     for (int i = 1; i < N; i++)
         workers.emplace_back([&, i] {  // one host thread per device
             rt_context* p = c->peers[i - 1];
-            rcs[i] = render_impl(p, s->replicas[i - 1], cam, &cfgs[i], p->pf_rgb, p->pf_n, p->stream, &st[i]);
+            rcs[i] = render_impl(p, s->replicas[i - 1], cam, &cfgs[i], p->pf_rgb, p->pf_n, p->stream, &st[i],
+                                 sub_world > 1 ? (uint32_t)i : 0u, sub_world);
             if (rcs[i] != RT_OK) errs[i] = g_err;  // g_err is thread-local
         });
-    rcs[0] = render_impl(c, s, cam, &cfgs[0], d_rgb, d_n, stream, &st[0]);
+    rcs[0] = render_impl(c, s, cam, &cfgs[0], d_rgb, d_n, stream, &st[0], 0u, sub_world);
     if (rcs[0] != RT_OK) errs[0] = g_err;
     for (auto& t : workers) t.join();
     for (int i = 0; i < N; i++)

@@ -707,8 +707,19 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
 #ifndef RT_SORT_CLASSES
 #define RT_SORT_CLASSES 5
 #endif
+#undef RT_SHADE_BOUND
+#define RT_SHADE_BOUND_RULE(F) ((F) <= RT_SHADE4_MAXFEAT ? 4 : (feat_three_waves(F) && RT_SHADE3_MAXFEAT >= 3 ? 3 : RT_SHADE_WAVES))
+#ifdef RT_F32
+#ifndef RT_F32_SHADE_WAVES
+#define RT_F32_SHADE_WAVES 4  // the binary32 single-lobe instances need 127-138 VGPRs: 4 waves/SIMD with a few spills
+                              // (measured: C4 k_shade 628 -> 553 ms, C3 90.6 -> 78.6; at 5 waves 791 / 91.8)
+#endif
+#define RT_SHADE_BOUND(F) (feat_three_waves(F) ? RT_F32_SHADE_WAVES : RT_SHADE_BOUND_RULE(F))
+#else
+#define RT_SHADE_BOUND(F) RT_SHADE_BOUND_RULE(F)
+#endif
 template <int FEAT>
-__global__ __launch_bounds__(256, FEAT <= RT_SHADE4_MAXFEAT ? 4 : (feat_three_waves(FEAT) && RT_SHADE3_MAXFEAT >= 3 ? 3 : RT_SHADE_WAVES)) void k_shade(DevScene sc, PathState in, PathState out, Ctl* ctl, uint32_t it_abs,
+__global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc, PathState in, PathState out, Ctl* ctl, uint32_t it_abs,
                                                uint32_t max_depth, uint32_t* queue_out, f64_t* lfx, f64_t* lfy,
                                                f64_t* lfz, DevStats* stats) {
     const uint32_t it = it_abs % kRing, itn = (it_abs + 1) % kRing;

@@ -1,18 +1,36 @@
 """Multi-GPU image-plane sharding: one process per GPU, tiles interleaved over ranks, film gather.
 
-The reference already farms 16x16 tiles to worker threads (src/render.rs:49-71); here tile k
-(row-major) belongs to rank k % world (rt_render_cfg.tile_rank / tile_world).  Pixels are
+The reference already farms 16x16 tiles to worker threads (src/render.rs:49-71); here tile
+(tx, ty) belongs to rank rt_tile_owner(tx, ty, world) = (tx + ty * stride) % world (include/rt_abi.h;
+rt_render_cfg.tile_rank / tile_world).  Pixels are
 independent (RNG keyed by seed, pixel, sample), so the only exchange step of the whole path is the
 final framebuffer gather to rank 0.  `gather_film` packs each rank's own pixels and sends them
 straight to the root (torch.distributed.gather = point-to-point sends on RCCL, one xGMI link per
 peer) -- 1/world of the bytes a full-frame reduce would move; `reduce_film` is the simple variant.
 Backends: "nccl" (= RCCL on ROCm) on GPUs, "gloo" in the CPU tests.
 """
+import math
+
 import numpy as np
 import torch
 import torch.distributed as dist
 
 TILE_SIZE = 16  # src/consts.rs:10
+
+
+def tile_stride(world):
+    """include/rt_abi.h: rt_tile_stride -- the integer nearest to world / golden ratio that is coprime to world."""
+    if world <= 1:
+        return 0
+    s = max((world * 618034 + 500000) // 1000000, 1)
+    while math.gcd(s, world) != 1:
+        s += 1
+    return s % world
+
+
+def tile_owner(tx, ty, world):
+    """include/rt_abi.h: rt_tile_owner -- rank-1 lattice: every tile row and every tile column visits all ranks in turn."""
+    return (tx + ty * tile_stride(world)) % world if world > 1 else 0
 
 
 def owned_pixels(width, height, rank, world, tile_size=TILE_SIZE, window=None):
@@ -22,9 +40,9 @@ def owned_pixels(width, height, rank, world, tile_size=TILE_SIZE, window=None):
     th = (height + tile_size - 1) // tile_size
     out = []
     for k in range(tw * th):
-        if k % world != rank:
-            continue
         tx, ty = k % tw, k // tw
+        if tile_owner(tx, ty, world) != rank:
+            continue
         ys = np.arange(ty * tile_size, min((ty + 1) * tile_size, height))
         xs = np.arange(tx * tile_size, min((tx + 1) * tile_size, width))
         ys = ys[(ys >= y0) & (ys < y1)]

@@ -4,6 +4,7 @@ The per-rank films come from the CPU oracle (test infrastructure); what is under
 product's sharding + gather code (rustraytracer_amd/dist.py) and the tile ownership rule that
 rt_render_cfg.tile_rank / tile_world implement on the GPU.
 """
+import math
 import os
 import socket
 import subprocess
@@ -99,3 +100,23 @@ def test_owned_pixels_partition():
     p = rd.owned_pixels(W, H, 1, 2, window=win)
     ys, xs = p // W, p % W
     assert xs.min() >= 8 and xs.max() < 40 and ys.min() >= 4 and ys.max() < 30
+
+
+def test_tile_owner_rule_matches_the_exported_function():
+    """include/rt_abi.h: rt_tile_owner -- the library's export, dist.py's mirror and the documented properties:
+    every tile row and every tile column deals its tiles to all ranks in turn (a row of 120 tiles, as in the
+    1920-wide headline image, must not hand whole columns to one rank)."""
+    from rustraytracer_amd import _ffi as F
+    L = F.lib()
+    for world in (1, 2, 3, 4, 5, 6, 7, 8, 12, 16, 64):
+        s = rd.tile_stride(world)
+        assert world == 1 or math.gcd(s, world) == 1
+        for ty in range(0, 70, 7):
+            for tx in range(0, 130, 11):
+                assert L.rt_tile_owner(tx, ty, world) == rd.tile_owner(tx, ty, world) < max(world, 1)
+        row = [rd.tile_owner(tx, 5, world) for tx in range(world)]
+        col = [rd.tile_owner(9, ty, world) for ty in range(world)]
+        assert sorted(row) == sorted(col) == list(range(world))
+    # 120 tiles per row, 8 ranks: a rank's tiles are not whole columns
+    cols = {tx for ty in range(68) for tx in range(120) if rd.tile_owner(tx, ty, 8) == 3}
+    assert len(cols) == 120
