@@ -1435,6 +1435,7 @@ __global__ __launch_bounds__(256) void k_wf_setup(const rt_ray* __restrict__ ray
         ctl->n_rays[0] = n;
         ctl->n_active[0] = n;
         ctl->head[0] = 0;
+        for (int x = 0; x < 8; x++) ctl->xhead[0][x][0] = 0;
     }
     if (i >= n) return;
     const rt_ray r = rays[i];

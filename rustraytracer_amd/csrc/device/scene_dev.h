@@ -146,6 +146,8 @@ struct Ctl {
     uint32_t head[kRing];
     // written by k_plan for the k_generate that follows it
     uint32_t gen_count, gen_first, gen_slot, gen_q;
+    // (RT_XCD_QUEUE) one queue head per XCD and iteration (ring of 4), each on its own 128-B line
+    uint32_t xhead[4][8][32];
 };
 
 // The batch being rendered, shared by both lanes.
