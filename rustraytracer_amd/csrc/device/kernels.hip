@@ -26,6 +26,9 @@
 // independent of how tiles are split over GPUs.
 #include "shading.h"
 
+#ifndef RT_QUEUE_BY_KIND
+#define RT_QUEUE_BY_KIND 1  // k_shade queues a block's rays kind by kind (0: wave by wave)
+#endif
 #ifndef RT_XCD_QUEUE
 #define RT_XCD_QUEUE 1  // the ray queue in eight parts, one per XCD (k_trace); 0 = one head for all waves
 #endif
@@ -850,7 +853,7 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc
         lfy[og] = a.L.y;
         lfz[og] = a.L.z;
     }
-    // ---- rays of the next bounce: one queue reservation per block, laid out wave by wave as
+    // ---- rays of the next bounce: one queue reservation per block, laid out as
     // [extension][shadow][probe]; statistics: one atomic per block and counter, on this block's shard
     {
         const unsigned long long me = __ballot(r.emit_ext), ms = __ballot(r.emit_sh), mp = __ballot(r.emit_pr);
@@ -878,12 +881,34 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc
             if (tv) atomicAdd(&sh->vertices, (unsigned long long)tv);
         }
         __syncthreads();
+        const unsigned long long below = (1ull << lane) - 1ull;
+#if RT_QUEUE_BY_KIND
+        // the block's rays kind by kind -- [extension of the 4 waves][shadow ...][probe ...] -- so that a traversal
+        // wave's 128-entry reservation is mostly one kind (shadow rays all run towards the light, probes and
+        // extensions anywhere): k_trace -0.6 % (C4) / -2.9 % (C3) / -2.6 % (C2) against wave-by-wave order
+        uint32_t oe = s_base[1], osd = 0, op = 0, te = 0, tsd = 0;
+        for (uint32_t w = 0; w < 4; w++) {
+            if (w < wave) {
+                oe += s_cnt[w][1];
+                osd += s_cnt[w][2];
+                op += s_cnt[w][3];
+            }
+            te += s_cnt[w][1];
+            tsd += s_cnt[w][2];
+        }
+        osd += s_base[1] + te;
+        op += s_base[1] + te + tsd;
+        if (r.emit_ext) queue_out[oe + (uint32_t)__popcll(me & below)] = os | (kRayExt << 30);
+        if (r.emit_sh) queue_out[osd + (uint32_t)__popcll(ms & below)] = os | (kRayShadow << 30);
+        if (r.emit_pr) queue_out[op + (uint32_t)__popcll(mp & below)] = os | (kRayProbe << 30);
+        (void)cp;
+#else
         uint32_t off = s_base[1];
         for (uint32_t w = 0; w < wave; w++) off += s_cnt[w][1] + s_cnt[w][2] + s_cnt[w][3];
-        const unsigned long long below = (1ull << lane) - 1ull;
         if (r.emit_ext) queue_out[off + (uint32_t)__popcll(me & below)] = os | (kRayExt << 30);
         if (r.emit_sh) queue_out[off + ce + (uint32_t)__popcll(ms & below)] = os | (kRayShadow << 30);
         if (r.emit_pr) queue_out[off + ce + cs + (uint32_t)__popcll(mp & below)] = os | (kRayProbe << 30);
+#endif
     }
     RT_PROF(9)
     RT_PROF_FLUSH

@@ -1,6 +1,5 @@
 #!/bin/bash
 V=$PWD/rustraytracer_amd/csrc/build/variants
-RT_AMD_LIB=$V/xqs.so timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_arms.py -x -q -m gpu 2>&1 | tail -2
 run() { label=$1; wl=$2; shift 2
   env "$@" timeout 900 python bench.py --workload $wl --no-cpu-baseline --no-extra --steps 3 --warmup 1 > gpurun_out/tmp.json 2>gpurun_out/tmp.err
   python - "$label $wl" <<'PY'
@@ -11,7 +10,10 @@ try:
 except Exception as e: print(sys.argv[1],'FAILED',e, open('gpurun_out/tmp.err').read()[-300:])
 PY
 }
-for wl in c4 c3 c2; do
-run "xq" $wl RT_AMD_LIB=$V/xq.so
-run "xq+shade" $wl RT_AMD_LIB=$V/xqs.so
+for wl in c4 c3; do
+run "base" $wl X=1
+run "nt loads" $wl RT_AMD_LIB=$V/nt1.so
+run "nt stores" $wl RT_AMD_LIB=$V/nt2.so
+run "nt both" $wl RT_AMD_LIB=$V/nt3.so
+run "base again" $wl X=1
 done
