@@ -5,6 +5,7 @@ Python or CPU fallback for any compute entry point.
 """
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RT_AMD_LIB: load another build of the same library (kernel-variant experiments, tools/variants.sh)
@@ -151,6 +152,30 @@ HOST_SYMBOLS = [
 _lib = None
 
 
+def _one_hip_runtime():
+    """Keep ONE HIP runtime in the process when PyTorch is installed.  The torch wheel bundles its own
+    libamdhip64.so (SONAME libamdhip64.so.7) and its libraries ask for it as "libamdhip64.so"; librt_amd.so asks for
+    "libamdhip64.so.7".  With torch imported first the loader hands librt_amd.so torch's copy (SONAME match); the
+    other way round /opt/rocm's copy is loaded first, torch's request does not match its SONAME, a second runtime
+    comes in beside it and torch then finds "No HIP GPUs" -- and device pointers / streams could not be shared
+    anyway.  Loading torch's copy by path first makes both orders end in the same single runtime (the loader
+    recognises the file when torch asks for it).  Without torch nothing happens and /opt/rocm's runtime is used."""
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+            path = os.path.join(libdir, name)
+            if os.path.exists(path):
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass  # a torch without a usable HIP runtime: librt_amd.so loads /opt/rocm's
+
+
 def lib():
     """Load librt_amd.so (built in-tree by __graft_entry__.build()).  Raises if absent."""
     global _lib
@@ -160,6 +185,7 @@ def lib():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no fallback path.")
+    _one_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.rt_last_error.restype = C.c_char_p

@@ -175,10 +175,10 @@ __global__ __launch_bounds__(256) void k_generate(PathState st, rt_camera cam, C
     (void)rng_next(rng);  // rand_range(t0, t1)
     st3(st.ox, st.oy, st.oz, slot, origin + offset);
     st3(st.dx, st.dy, st.dz, slot, dir - offset);
-    st3(st.bx, st.by, st.bz, slot, white());
-    st3(st.lx, st.ly, st.lz, slot, black());
+    // (beta = 1 and L = 0 are not written: kFresh tells shade_a -- 48 of this kernel's 116 B per sample, and the kernel
+    // is bound by its HBM writes)
     st.rng[slot] = rng;
-    st.flags[slot] = 0u;
+    st.flags[slot] = kFresh;
     st.orig[slot] = g;
     queue[ctl->gen_q + idx] = slot | (kRayExt << 30);
 }
@@ -522,7 +522,7 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool va
     a.L = black();
     a.o = black();
     if (a.live) {
-        a.L = l_in;
+        a.L = (fl & kFresh) ? black() : l_in;
         a.o = o_in;
         // ---- fold the previous vertex's direct lighting
         if (fl & (kHasShadow | kHasProbe)) {
@@ -580,7 +580,7 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool va
     if (active) {
         const int32_t hp = hp_in;
         a.d = d_in;
-        a.beta = beta_in;
+        a.beta = (fl & kFresh) ? white() : beta_in;
         is_some = hp >= 0;
         if (is_some) is_some = hit_record(sc, hp, hs_in, a.o, a.d, kSmall, kInf, a.rec);
         RT_PROF(1)

@@ -124,6 +124,7 @@ constexpr uint32_t kFoldOnly = 1u << 9;
 constexpr uint32_t kHasShadow = 1u << 10;
 constexpr uint32_t kHasProbe = 1u << 11;
 constexpr uint32_t kDead = 1u << 12;  // slot allocated for a vertex whose path then ended with nothing pending
+constexpr uint32_t kFresh = 1u << 13;  // a camera sample k_generate has just written: beta = 1, L = 0 are implied, not stored
 constexpr uint32_t kLightShift = 16;
 
 // queue entry = slot | kind << 30
