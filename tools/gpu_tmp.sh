@@ -1,6 +1,4 @@
 #!/bin/bash
-V=$PWD/rustraytracer_amd/csrc/build/variants
-timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_arms.py tests/test_gpu_abi2.py -x -q -m gpu 2>&1 | tail -2
 run() { label=$1; wl=$2; shift 2
   env "$@" timeout 900 python bench.py --workload $wl --no-cpu-baseline --no-extra --steps 3 --warmup 1 > gpurun_out/tmp.json 2>gpurun_out/tmp.err
   python - "$label $wl" <<'PY'
@@ -11,7 +9,10 @@ try:
 except Exception as e: print(sys.argv[1],'FAILED',e, open('gpurun_out/tmp.err').read()[-300:])
 PY
 }
-for wl in c4 c3 c2; do
-run "old" $wl RT_AMD_LIB=$V/old.so
-run "fresh flag" $wl X=1
+for wl in c4 c3; do
+run "pad 0" $wl RT_STATE_PAD=0
+run "pad 256" $wl RT_STATE_PAD=256
+run "pad 4352" $wl RT_STATE_PAD=4352
+run "pad 69888" $wl RT_STATE_PAD=69888
+run "pad 1052928" $wl RT_STATE_PAD=1052928
 done
