@@ -1186,17 +1186,19 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
         }
 #endif
         if (getenv("RT_DIAG")) {
-            unsigned long long d[4] = {0, 0, 0, 0};
-            for (int i = 0; i < kStatShards; i++)
+            unsigned long long d[4] = {0, 0, 0, 0}, over64 = 0, over256 = 0;
+            for (int i = 0; i < kStatShards; i++) {
                 for (int q = 0; q < 4; q++) d[q] += shards[i].pad[8 + q];
+                over64 += shards[i].pad[4];
+                over256 += shards[i].pad[5];
+            }
             fprintf(stderr, "[rt diag] node rounds %llu avg lanes %.1f | prim rounds %llu avg lanes %.1f\n", d[0],
                     d[0] ? (double)d[1] / d[0] : 0.0, d[2], d[2] ? (double)d[3] / d[2] : 0.0);
             // instrumented build only: short trace launches (in-kernel time, 10 ns ticks) and the longest traversals
             fprintf(stderr, "[rt diag] trace launches under 4096 rays: %llu, avg in-kernel us %.1f, avg rays %.1f | "
                             "max steps per ray %llu, rays over 64 steps %llu, over 256 steps %llu\n",
                     shards[0].pad[1], shards[0].pad[1] ? shards[0].pad[0] / 100.0 / shards[0].pad[1] : 0.0,
-                    shards[0].pad[1] ? (double)shards[0].pad[2] / shards[0].pad[1] : 0.0, shards[0].pad[3],
-                    shards[0].pad[4], shards[0].pad[5]);
+                    shards[0].pad[1] ? (double)shards[0].pad[2] / shards[0].pad[1] : 0.0, shards[0].pad[3], over64, over256);
         }
         stats->tail_rays = ds.tail_rays;
         stats->tail_nodes_fetched = ds.tail_nodes;
@@ -1207,8 +1209,9 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
 }
 
 // ------------------------------------------------------------------ multi-device render
-// Tile k (row-major, rt_render_cfg.tile_size) belongs to the caller if k % world == rank; of the caller's tiles,
-// device i of the context takes every N-th: k % (world * N) == rank + world * i.  Pixels are independent and keyed
+// Tile (tx, ty) belongs to rank rt_tile_owner(tx, ty, world) (include/rt_abi.h).  One caller: the context's N devices
+// are the lattice's N ranks; a caller that is one of several keeps its own tiles and deals them to its devices in
+// turn.  Pixels are independent and keyed
 // by (seed, pixel, sample), so the film is bit-identical to a one-device render.  The only exchange is the final
 // gather: each further device packs its own pixels ({r, g, b, n} as four doubles), copies them straight to the
 // primary device (hipMemcpyPeerAsync: one xGMI link per peer, 1/N of the bytes a full-frame reduce would move) where

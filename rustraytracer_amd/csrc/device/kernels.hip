@@ -256,6 +256,7 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
     bool wb = false;  // this lane's finished ray still has to write its result (done in refill rounds)
     uint32_t ray_steps0 = 0;
     uint32_t diag_rounds[4] = {0, 0, 0, 0};  // wave-uniform diagnostics (instrumented build only)
+    uint32_t diag_max_steps = 0, diag_over[2] = {0, 0};  // per lane: longest traversal, rays over 64 / 256 steps
     bool exhausted = false;  // wave-uniform: the queue and this wave's reservation have no more entries
     uint32_t slot_kind = 0;
     uint32_t res_next = 0, res_end = 0;  // wave-uniform: [res_next, res_end) is reserved for this wave
@@ -391,9 +392,9 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
         if (has_ray && tv.done) {
             if (COUNT) {  // diagnostic: longest traversal, and how many rays needed more than 64 / 256 steps
                 const uint32_t steps = tc.nodes + tc.tris + tc.others - ray_steps0;
-                atomicMax(&stats->pad[3], (unsigned long long)steps);
-                if (steps > 64u) atomicAdd(&stats->pad[4], 1ull);
-                if (steps > 256u) atomicAdd(&stats->pad[5], 1ull);
+                diag_max_steps = steps > diag_max_steps ? steps : diag_max_steps;
+                diag_over[0] += steps > 64u;
+                diag_over[1] += steps > 256u;
             }
             wb = true;
             has_ray = false;
@@ -406,6 +407,14 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
             atomicAdd(&stats->pad[2], (unsigned long long)n);
         }
         DevStats* sh = stat_shard(stats);
+        // (per lane and launch, not per ray: a same-address atomic per finished ray made this build 8x slower)
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t other = (uint32_t)__shfl_xor((int)diag_max_steps, o, 64);
+            diag_max_steps = other > diag_max_steps ? other : diag_max_steps;
+        }
+        if (lane == 0) atomicMax(&stats->pad[3], (unsigned long long)diag_max_steps);
+        if (diag_over[0]) atomicAdd(&sh->pad[4], (unsigned long long)diag_over[0]);
+        if (diag_over[1]) atomicAdd(&sh->pad[5], (unsigned long long)diag_over[1]);
         if (lane == 0)
             for (int q = 0; q < 4; q++) atomicAdd(&sh->pad[8 + q], (unsigned long long)diag_rounds[q]);
         atomicAdd(&sh->nodes, (unsigned long long)tc.nodes);
