@@ -196,6 +196,38 @@ struct Builder {
                     }
                 }
             }
+            // One more candidate: the primitive of largest surface area alone against all the others.  Binning by
+            // centroids cannot see it -- a 2e4-wide floor rect has its centroid among the mesh's -- and a box that
+            // large left inside a subtree is fetched by every ray on the way to what it is mixed with (two_dragons,
+            // 16 bins: three nested nodes with the floor's box, 9.1 node fetches per ray against 7.3 once it is
+            // split off at the root).  Only evaluated when one primitive makes up a third of the node's area.
+            if (n > 2) {
+                size_t big = b;
+                double big_area = -1.0;
+                for (size_t i = b; i < e; i++) {
+                    Box pb;
+                    pb.reset();
+                    pb.grow(prims[order[i]].bbox_min, prims[order[i]].bbox_max);
+                    const double a = pb.half_area();
+                    if (a > big_area) {
+                        big_area = a;
+                        big = i;
+                    }
+                }
+                if (big_area * 3.0 >= bin[me].box.half_area()) {
+                    Box rest;
+                    rest.reset();
+                    for (size_t i = b; i < e; i++)
+                        if (i != big) rest.grow(prims[order[i]].bbox_min, prims[order[i]].bbox_max);
+                    const double cost = big_area + rest.half_area() * (double)(n - 1);
+                    if (cost < best_cost) {
+                        std::swap(order[b], order[big]);
+                        mid = b + 1;
+                        split_done = true;
+                        best_axis = -1;
+                    }
+                }
+            }
             if (best_axis >= 0) {
                 double ext = cmx[best_axis] - cmn[best_axis];
                 double scale = (double)NB / ext;

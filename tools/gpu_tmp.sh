@@ -1,11 +1,15 @@
 #!/bin/bash
 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
-python - <<'PY'
-import time, torch, bench, rustraytracer_amd as rr
-b = bench.Bench("c4", 0, 1, 0, "cuda")
-b.step(); torch.cuda.synchronize()
-t0=time.time(); st=b.step(); torch.cuda.synchronize(); t1=time.time()
-stc=b.counted(); t2=time.time()
-print("plain %.2f s, counted %.2f s; nodes/ray %.3f tris/ray %.3f" % (t1-t0, t2-t1, stc.nodes_fetched/stc.rays, stc.tris_tested/stc.rays))
+run() { label=$1; wl=$2; shift 2
+  env "$@" timeout 900 python bench.py --workload $wl --no-cpu-baseline --no-extra --steps 3 --warmup 1 > gpurun_out/tmp.json 2>gpurun_out/tmp.err
+  python - "$label $wl" <<'PY'
+import json,sys
+try:
+    d=json.load(open('gpurun_out/tmp.json')); r=d['roofline']; k=r['kernels']['k_shade']
+    print('%-22s Mrays/s %.0f ms %.2f trace %.2f shade %.2f nodes/ray %.3f tris/ray %.3f frac %.3f'%(sys.argv[1],d['value'],d['ms_per_step'],r['avg_launch_ms']*r['launches_per_step'],k['avg_launch_ms']*k['launches_per_step'], r['nodes_per_ray'], r['tris_per_ray'], r['frac']))
+except Exception as e: print(sys.argv[1],'FAILED',e, open('gpurun_out/tmp.err').read()[-300:])
 PY
-RT_DIAG=1 python bench.py --workload c2 --no-cpu-baseline --no-extra --steps 2 2>&1 | grep "rt diag" | tail -2
+}
+for wl in c4 c3 c2 hdr1; do
+run "outlier split" $wl X=1
+done
