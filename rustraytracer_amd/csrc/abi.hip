@@ -442,6 +442,28 @@ struct HostLeafData {
     uint32_t depth = 0;
     uint64_t n_tri = 0;
 };
+// scene_dev.h: leaf_trav -- the leaf slots re-laid for the traversal kernel, one 128-B line each (bit copies)
+__global__ __launch_bounds__(256) void k_make_leaf_trav(const double* __restrict__ leaf_tri, const uint32_t* __restrict__ leaf_prim,
+                                                       uint32_t n, double* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long* s = reinterpret_cast<const unsigned long long*>(leaf_tri) + (size_t)i * 9;
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(out) + (size_t)i * 16;
+    const uint32_t e = leaf_prim[i];
+    if (e & kLeafOther) {
+        for (int k = 0; k < 6; k++) o[k] = s[k];
+        for (int k = 6; k < 15; k++) o[k] = 0ull;
+    } else {
+        for (int c = 0; c < 3; c++)
+            for (int v = 0; v < 3; v++) o[c * 3 + v] = s[v * 3 + c];
+        for (int v = 0; v < 3; v++) {
+            o[9 + v] = s[v * 3 + 0];
+            o[12 + v] = s[v * 3 + 1];
+        }
+    }
+    o[15] = (unsigned long long)e;
+}
+
 static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cache);
 
 // The builder emits nodes depth-first.  Move the top of the tree -- the first `n_top` nodes met breadth-first from the
@@ -652,6 +674,17 @@ static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cac
         depth = cache.depth;
         n_tri = cache.n_tri;
     }
+    if (np > 0) {  // the traversal kernel's one-line-per-slot copy of the leaf slots (scene_dev.h: leaf_trav)
+        double* trav = nullptr;
+        HIP_TRY(hipMalloc((void**)&trav, np * 16 * sizeof(double)));
+        t->allocs.push_back(trav);
+        hipLaunchKernelGGL(k_make_leaf_trav, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, t->ctx->stream, d.leaf_tri,
+                           d.leaf_prim, (uint32_t)np, trav);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+        d.leaf_trav = trav;
+        t->info.device_bytes_total += np * 16 * sizeof(double);
+    }
     t->info.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     t->info.build_flags = flags;
     d.n_prims = (uint32_t)np;
@@ -666,8 +699,9 @@ static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cac
     t->info.n_bvh_nodes = d.n_nodes;
     t->info.bvh_depth = depth;
     t->info.node_bytes = sizeof(DevNode);
+    // bytes a primitive test requests from its leaf_trav line: the nine coordinates / v[5] + meta, + the index word
     t->info.tri_bytes = 9 * sizeof(double) + sizeof(uint32_t);
-    t->info.other_bytes = 6 * sizeof(double) + sizeof(uint32_t);  // v[5] + meta in the leaf slot, + id
+    t->info.other_bytes = 6 * sizeof(double) + sizeof(uint32_t);
     t->committed = true;
     return RT_OK;
 }

@@ -692,17 +692,22 @@ RTD void node_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
 // SIMPLE: the scene has no sphere and no transformed rect (DevScene::simple_others), so the sphere / rect arm
 // of a leaf is a plain axis-aligned rect test -- an instance of the traversal kernel without that code needs
 // 11 VGPRs less (113 instead of 124) and is 2-3 % faster.
+struct __attribute__((packed, aligned(8))) LeafNine {
+    f64_t v[9];  // RT_KEEP_F64
+};
 template <bool COUNT, bool SIMPLE = false>
 RTD void leaf_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
     const double tmin = tv.tmin, tmax = tv.tmax;
     const uint32_t code = (uint32_t)(-1 - tv.cur);
     const uint32_t first = (code & ~kLeafCodeOther) >> 3, count = (code & 7u) + 1u;
     const uint32_t slot = first;
-    const uint32_t e = sc.leaf_prim[slot];
 #ifdef RT_F32
+    const uint32_t e = sc.leaf_prim[slot];
     const float* tvp = sc.leaf_tri32 + (size_t)slot * 9;  // RT_KEEP_F64
 #else
-    const f64_t* tvp = sc.leaf_tri + (size_t)slot * 9;
+    // one aligned 128-B line per slot (scene_dev.h: leaf_trav): geometry and the primitive index word
+    const f64_t* rec = sc.leaf_trav + (size_t)slot * 16;
+    const uint32_t e = reinterpret_cast<const uint32_t*>(rec)[30];
 #endif
     double t = 0.0;
     int32_t pi = -1;
@@ -711,18 +716,23 @@ RTD void leaf_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
         // The nine coordinates are fetched in the ray's permuted axis order (kx, ky, kz), so the sheared
         // test needs no per-triangle shuffle; the addresses do not depend on `e` (loads issue together).
         const int kz = tv.trr.kz, kx = kz == 2 ? 0 : kz + 1, ky = kx == 2 ? 0 : kx + 1;
-#ifdef RT_F32
-        const float *px = tvp + kx, *py = tvp + ky, *pz = tvp + kz;  // RT_KEEP_F64
-#else
-        const f64_t* px = tvp + kx;
-        const f64_t* py = tvp + ky;
-        const f64_t* pz = tvp + kz;
-#endif
         const D3 op = tv.op, ip = tv.ip;
         if (COUNT) tc->tris++;
+#ifdef RT_F32
+        const float *px = tvp + kx, *py = tvp + ky, *pz = tvp + kz;  // RT_KEEP_F64
         const D3 p0t = d3(px[0] - op.x, py[0] - op.y, pz[0] - op.z);
         const D3 p1t = d3(px[3] - op.x, py[3] - op.y, pz[3] - op.z);
         const D3 p2t = d3(px[6] - op.x, py[6] - op.y, pz[6] - op.z);
+#else
+        // the 72 contiguous bytes from double 3 * kx: components kx, ky, kz of the three vertices (four 16-B loads
+        // and an 8-B one on the slot's line; the window never leaves it)
+        LeafNine w;
+        __builtin_memcpy(&w, rec + kx * 3, sizeof(w));
+        (void)ky;
+        const D3 p0t = d3(w.v[0] - op.x, w.v[3] - op.y, w.v[6] - op.z);
+        const D3 p1t = d3(w.v[1] - op.x, w.v[4] - op.y, w.v[7] - op.z);
+        const D3 p2t = d3(w.v[2] - op.x, w.v[5] - op.y, w.v[8] - op.z);
+#endif
         // The reference tests the leaf's own f64 box on the ORIGINAL interval (hittable.rs:625):
         // ((min_i p_i) - o) * inv.  fl(a - o) is monotone in a, so min/max commute with the subtraction
         // and the corner offsets are the min/max of the translated vertices (bit-identical); the axis order
@@ -746,7 +756,11 @@ RTD void leaf_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
             const rt_primitive& pr = sc.prims[pi];
             const DevMesh& m = sc.meshes[pr.mesh_index];
             if (m.uv) {
+#ifdef RT_F32
                 const D3 p0 = d3(tvp[0], tvp[1], tvp[2]), p1 = d3(tvp[3], tvp[4], tvp[5]), p2 = d3(tvp[6], tvp[7], tvp[8]);
+#else
+                const D3 p0 = d3(rec[0], rec[3], rec[6]), p1 = d3(rec[1], rec[4], rec[7]), p2 = d3(rec[2], rec[5], rec[8]);
+#endif
                 TriUv uv = tri_uvs(m, m.ind[pr.tri_ind], m.ind[pr.tri_ind + 1], m.ind[pr.tri_ind + 2]);
                 D3 du, dv;
                 hit = tri_dpdu(p0, p1, p2, uv, du, dv);
@@ -764,9 +778,9 @@ RTD void leaf_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
         const double v0 = tvp[0], v1 = tvp[1], v2 = tvp[2], v3 = tvp[3], v4 = tvp[4];
         const uint64_t meta = (uint64_t)__float_as_uint(tvp[5]) | ((uint64_t)__float_as_uint(tvp[6]) << 32);
 #else
-        const f64x2_t q0 = *reinterpret_cast<const f64x2_t*>(tvp);
-        const f64x2_t q1 = *reinterpret_cast<const f64x2_t*>(tvp + 2);
-        const f64x2_t q2 = *reinterpret_cast<const f64x2_t*>(tvp + 4);
+        const f64x2_t q0 = *reinterpret_cast<const f64x2_t*>(rec);
+        const f64x2_t q1 = *reinterpret_cast<const f64x2_t*>(rec + 2);
+        const f64x2_t q2 = *reinterpret_cast<const f64x2_t*>(rec + 4);
         const double v0 = q0.x, v1 = q0.y, v2 = q1.x, v3 = q1.y, v4 = q2.x;
         const uint64_t meta = dm_bits(q2.y);
 #endif

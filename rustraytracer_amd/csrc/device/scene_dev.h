@@ -75,6 +75,14 @@ struct DevScene {
     const DevNode* nodes;
     const uint32_t* leaf_prim;  // leaf order -> prim index | kLeafOther
     const double* leaf_tri;     // leaf order -> 9 doubles p0,p1,p2 (triangles), 72 B
+    // The traversal kernel's own copy of a leaf slot, one aligned 128-B line (16 doubles) per slot, so that a primitive
+    // test touches ONE cache line instead of 2.4 (a 72-B record straddles lines 7 times in 16, the primitive index
+    // was a gather of its own) and fetches it with 6 loads instead of 10:
+    //   triangle: x0 x1 x2 y0 y1 y2 z0 z1 z2 x0 x1 x2 y0 y1 y2 -- the nine coordinates in the ray's permuted axis
+    //             order (kx, ky, kz) are the 72 contiguous bytes from double 3 * kx;
+    //   sphere / rect: v[0..4], {kind, transform index} (as in leaf_tri);
+    //   both: the last double holds the leaf_prim word (primitive index | kLeafOther) in its low half.
+    const double* leaf_trav;
     // Shading side of a triangle's leaf slot, so that rebuilding the winner's hit record needs one dependent
     // fetch (slot -> vertices + normals + meta) instead of five (prim -> mesh -> indices -> positions/normals):
     const double* leaf_nrm;     // leaf order -> 9 doubles n0,n1,n2 (null: no mesh has normals)

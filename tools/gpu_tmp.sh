@@ -11,5 +11,5 @@ except Exception as e: print(sys.argv[1],'FAILED',e, open('gpurun_out/tmp.err').
 PY
 }
 for wl in c4 c3 c2 hdr1; do
-run "outlier split" $wl X=1
+run "leaf_trav" $wl X=1
 done
