@@ -144,6 +144,7 @@ __global__ __launch_bounds__(256) void kb_morton(const rt_primitive* __restrict_
     if (i >= n) return;
     const rt_primitive& p = prims[i];
     ull q[3];
+    double scene_ext = 0.0, own_ext = 0.0;
     for (int a = 0; a < 3; a++) {
         const double lo = dec_f64(g->cmin[a]), hi = dec_f64(g->cmax[a]);
         const double c = (p.bbox_min[a] + p.bbox_max[a]) * 0.5;
@@ -151,8 +152,15 @@ __global__ __launch_bounds__(256) void kb_morton(const rt_primitive* __restrict_
         double f = ext > 0.0 ? (c - lo) / ext * 2097152.0 : 0.0;
         f = fmin(fmax(f, 0.0), 2097151.0);
         q[a] = (ull)f;
+        scene_ext = fmax(scene_ext, ext);
+        own_ext = fmax(own_ext, p.bbox_max[a] - p.bbox_min[a]);
     }
-    keys[i] = spread21(q[0]) | (spread21(q[1]) << 1) | (spread21(q[2]) << 2);
+    // A primitive that is large against the spread of the centroids (a floor rect 2e4 wide under a mesh, the walls
+    // of the Cornell box around the statue) would, sorted by its centroid, inflate every box between its leaf and
+    // the root.  Bit 63 -- free in a 63-bit Morton key -- sends such primitives to the root's second subtree: the
+    // radix tree splits on the highest differing bit first, so they never share an inner node with the small ones.
+    const ull large = (own_ext >= 0.25 * scene_ext && scene_ext > 0.0) ? (1ull << 63) : 0ull;
+    keys[i] = spread21(q[0]) | (spread21(q[1]) << 1) | (spread21(q[2]) << 2) | large;
     vals[i] = i;
 }
 
