@@ -169,13 +169,15 @@ class Bench:
 
 
 def timed(b, steps, warmup, barrier):
-    # one-off set-up that is not the measured work, whatever --warmup says: the library allocates its path pools and
-    # film staging at the first render, RCCL connects peers at the first gather (1 spp of the same image, untimed)
-    cfg = b.cfg
-    b.cfg = b.rr.make_cfg(b.W, b.H, 1, seed=0, tile_rank=b.rank, tile_world=b.world, paths_in_flight=b.pif,
-                          precision=b.precision)
-    b.step()
-    b.cfg = cfg
+    if warmup == 0:
+        # one-off set-up that is not the measured work: the library allocates its pools at the first render, RCCL
+        # connects peers at the first gather (1 spp of the same image, untimed).  With --warmup >= 1 the warm-up step
+        # does both, and the profiles stay free of these short launches.
+        cfg = b.cfg
+        b.cfg = b.rr.make_cfg(b.W, b.H, 1, seed=0, tile_rank=b.rank, tile_world=b.world, paths_in_flight=b.pif,
+                              precision=b.precision)
+        b.step()
+        b.cfg = cfg
     for _ in range(warmup):
         b.step()
     barrier()
