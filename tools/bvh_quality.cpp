@@ -162,6 +162,64 @@ static int trace(const Scene& s, V o, V dir, double tmax, double& t_hit, V& n_hi
     }
 }
 
+// ---- what a wider tree would fetch: the same tree re-collapsed to W children per node (a node keeps opening its
+// internal child of largest area while the result still fits), traversed the same way
+struct WideNode {
+    std::vector<int32_t> child;  // >= 0: wide node index, < 0: leaf code of the BVH4 (as DevNode::child)
+    std::vector<float> lo, hi;   // 3 floats per child
+};
+struct Wide {
+    std::vector<WideNode> nodes;
+    int width = 8;
+};
+static int32_t widen(const BvhOut& b, int32_t n4, Wide& w) {
+    struct C {
+        int32_t ref;
+        float lo[3], hi[3];
+    };
+    std::vector<C> kids;
+    auto push_children = [&](int32_t node) {
+        const DevNode& nd = b.nodes[node];
+        for (int k = 0; k < 4; k++)
+            if (nd.child[k] != kNoChild)
+                kids.push_back(C{nd.child[k], {nd.lo_x[k], nd.lo_y[k], nd.lo_z[k]}, {nd.hi_x[k], nd.hi_y[k], nd.hi_z[k]}});
+    };
+    push_children(n4);
+    for (;;) {
+        int best = -1;
+        double best_area = -1.0;
+        for (size_t i = 0; i < kids.size(); i++)
+            if (kids[i].ref >= 0) {
+                const DevNode& nd = b.nodes[kids[i].ref];
+                int nc = 0;
+                for (int k = 0; k < 4; k++) nc += nd.child[k] != kNoChild;
+                if ((int)kids.size() - 1 + nc > w.width) continue;
+                const double dx = (double)kids[i].hi[0] - kids[i].lo[0], dy = (double)kids[i].hi[1] - kids[i].lo[1],
+                             dz = (double)kids[i].hi[2] - kids[i].lo[2], a = dx * dy + dy * dz + dz * dx;
+                if (a > best_area) {
+                    best_area = a;
+                    best = (int)i;
+                }
+            }
+        if (best < 0) break;
+        const int32_t open = kids[best].ref;
+        kids.erase(kids.begin() + best);
+        push_children(open);
+    }
+    const int32_t me = (int32_t)w.nodes.size();
+    w.nodes.emplace_back();
+    for (const C& c : kids) {
+        const int32_t r = c.ref >= 0 ? widen(b, c.ref, w) : c.ref;
+        WideNode& wn = w.nodes[me];
+        wn.child.push_back(r);
+        for (int a = 0; a < 3; a++) {
+            wn.lo.push_back(c.lo[a]);
+            wn.hi.push_back(c.hi[a]);
+        }
+    }
+    return me;
+}
+
 static double sah_cost(const BvhOut& b) {
     // expected fetches of a random line that hits the root box: sum over nodes of area(node box) / area(root box),
     // a node's box being the union of its child boxes; leaves add their own area (one primitive test each)
@@ -197,6 +255,61 @@ static double sah_cost(const BvhOut& b) {
     std::printf("sah: node term %.3f leaf term %.3f (relative to the root box; the 2e4-wide floor dominates the root)\n",
                 total / root, leaf_sum / root);
     return (total + leaf_sum) / root;
+}
+
+static int trace_wide(const Scene& s, const Wide& w, V o, V dir, double tmax, Count& c) {
+    const double inv[3] = {1.0 / dir.x, 1.0 / dir.y, 1.0 / dir.z}, oo[3] = {o.x, o.y, o.z};
+    struct E {
+        int32_t node;
+        double t;
+    };
+    E stack[512];
+    int sp = 0;
+    int32_t cur = 0;
+    int best = -1;
+    double best_t = tmax;
+    c.rays++;
+    for (;;) {
+        if (cur >= 0) {
+            const WideNode& nd = w.nodes[cur];
+            c.nodes++;
+            E hit[16];
+            int nh = 0;
+            for (size_t k = 0; k < nd.child.size(); k++) {
+                double tn = 1e-3, tf = best_t;
+                for (int a = 0; a < 3; a++) {
+                    double t0 = (nd.lo[3 * k + a] - oo[a]) * inv[a], t1 = (nd.hi[3 * k + a] - oo[a]) * inv[a];
+                    if (t0 > t1) std::swap(t0, t1);
+                    if (t0 > tn) tn = t0;
+                    if (t1 < tf) tf = t1;
+                }
+                if (!(tf <= tn)) hit[nh++] = E{nd.child[k], tn};
+            }
+            std::sort(hit, hit + nh, [](const E& a, const E& b) { return a.t > b.t; });
+            for (int k = 0; k < nh; k++) stack[sp++] = hit[k];
+        } else {
+            const uint32_t code = (uint32_t)(-1 - cur) & ~kLeafCodeOther;
+            const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+            for (uint32_t i = 0; i < cnt; i++) {
+                c.prims++;
+                double t;
+                V n;
+                const uint32_t pi = s.bvh.order[first + i];
+                if (hit_prim(s, pi, o, dir, best_t, t, n) && t < best_t) {
+                    best_t = t;
+                    best = (int)pi;
+                }
+            }
+        }
+        for (;;) {
+            if (sp == 0) return best;
+            const E e = stack[--sp];
+            if (e.t <= best_t) {
+                cur = e.node;
+                break;
+            }
+        }
+    }
 }
 
 static unsigned long long rng_state = 88172645463325252ull;
@@ -236,6 +349,13 @@ int main(int argc, char** argv) {
             break;
         }
     Count cp, cb, cs, cb2;
+    Wide w8, w16;
+    w8.width = 8;
+    w16.width = 16;
+    widen(s.bvh, 0, w8);
+    widen(s.bvh, 0, w16);
+    std::printf("re-collapsed: %zu nodes of up to 8 children, %zu of up to 16\n", w8.nodes.size(), w16.nodes.size());
+    Count c8, c16;
     const V org{cam.origin[0], cam.origin[1], cam.origin[2]}, ulc{cam.upper_left_corner[0], cam.upper_left_corner[1], cam.upper_left_corner[2]};
     const V ho{cam.horizontal_offset[0], cam.horizontal_offset[1], cam.horizontal_offset[2]};
     const V vo{cam.vertical_offset[0], cam.vertical_offset[1], cam.vertical_offset[2]};
@@ -244,6 +364,8 @@ int main(int argc, char** argv) {
         double t;
         V n;
         int hit = trace(s, org, dir, 1e308, t, n, cp);
+        trace_wide(s, w8, org, dir, 1e308, c8);
+        trace_wide(s, w16, org, dir, 1e308, c16);
         V p = org + dir * t, wo = dir;
         for (int bounce = 0; bounce < 2 && hit >= 0; bounce++) {
             if (dot(n, wo) > 0.0) n = n * -1.0;
@@ -251,11 +373,15 @@ int main(int argc, char** argv) {
             double ts;
             V ns;
             trace(s, p, light_c - p, 1e308, ts, ns, cs);
+            trace_wide(s, w8, p, light_c - p, 1e308, c8);
+            trace_wide(s, w16, p, light_c - p, 1e308, c16);
             const double r1 = rnd(), r2 = rnd(), ph = 6.283185307179586 * r1, sr = std::sqrt(r2);
             const V a = std::fabs(n.x) > 0.9 ? V{0, 1, 0} : V{1, 0, 0}, tn = norm(cross(n, a)), bn = cross(n, tn);
             const V d2 = tn * (std::cos(ph) * sr) + bn * (std::sin(ph) * sr) + n * std::sqrt(1.0 - r2);
             Count& cc = bounce == 0 ? cb : cb2;
             hit = trace(s, p, d2, 1e308, t, n, cc);
+            trace_wide(s, w8, p, d2, 1e308, c8);
+            trace_wide(s, w16, p, d2, 1e308, c16);
             p = p + d2 * t;
             wo = d2;
         }
@@ -275,6 +401,8 @@ int main(int argc, char** argv) {
         all.prims += c->prims;
     }
     pr("all", all);
+    pr("all, 8-wide", c8);
+    pr("all, 16-wide", c16);
     rrh_scene_destroy(hs);
     return 0;
 }
