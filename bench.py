@@ -169,10 +169,9 @@ class Bench:
 
 
 def timed(b, steps, warmup, barrier):
-    if warmup == 0:
-        # one-off set-up that is not the measured work: the library allocates its pools at the first render, RCCL
-        # connects peers at the first gather (1 spp of the same image, untimed).  With --warmup >= 1 the warm-up step
-        # does both, and the profiles stay free of these short launches.
+    if warmup == 0 and b.world > 1:
+        # one-off set-up that is not the measured work: RCCL connects peers at the first gather (1 spp of the same
+        # image, untimed).  With --warmup >= 1 the warm-up step does it; single-GPU runs (the profiles) never need it.
         cfg = b.cfg
         b.cfg = b.rr.make_cfg(b.W, b.H, 1, seed=0, tile_rank=b.rank, tile_world=b.world, paths_in_flight=b.pif,
                               precision=b.precision)
