@@ -26,6 +26,9 @@
 // independent of how tiles are split over GPUs.
 #include "shading.h"
 
+#ifndef RT_SHADE_EARLY_EXIT
+#define RT_SHADE_EARLY_EXIT 1  // k_shade: waves with nothing to shade end before the block's barriers (0: they park)
+#endif
 #ifndef RT_QUEUE_BY_KIND
 #define RT_QUEUE_BY_KIND 1  // k_shade queues a block's rays kind by kind (0: wave by wave)
 #endif
@@ -840,11 +843,49 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc
     // a vertex that will be shaded gets its output slot now (dense, block-contiguous); if the path
     // then ends without pending light terms the slot is marked dead and skipped next bounce
     uint32_t os;
+    bool leader = threadIdx.x == 0;
+#if RT_SHADE_EARLY_EXIT
+    __shared__ uint32_t s_alive[4];
+#endif
     {   // one atomic per block: wave counts -> LDS -> block base -> per-lane slot
         const unsigned long long m = __ballot(a.will_shade);
-        if (lane == 0) s_cnt[wave][0] = (uint32_t)__popcll(m);
+#if RT_SHADE_EARLY_EXIT
+        // A wave without a vertex to shade -- escaped / fold-only / dead paths, which the dealing step gathers into
+        // whole waves -- writes its film values, reports zero counts and ENDS instead of parking at the block's two
+        // barrier pairs (a barrier waits only for the waves that are still alive).  Parked waves hold their 168
+        // registers and a wave slot while the block's other waves run shade_b: C4 (42 % of the slots are escaped
+        // paths) k_shade 741 -> 658 ms, C3 110.6 -> 101.3; the Lambert-only instance does not deal and sees nothing.
+        if (m == 0ull) {
+            if (a.live) {
+                const uint32_t og = a.orig;
+                lfx[og] = a.L.x;
+                lfy[og] = a.L.y;
+                lfz[og] = a.L.z;
+            }
+            if (lane == 0) {
+                s_cnt[wave][0] = 0u;
+                s_cnt[wave][1] = 0u;
+                s_cnt[wave][2] = 0u;
+                s_cnt[wave][3] = 0u;
+                s_alive[wave] = 0u;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the LDS writes have landed before the wave ends
+            return;
+        }
+#endif
+        if (lane == 0) {
+            s_cnt[wave][0] = (uint32_t)__popcll(m);
+#if RT_SHADE_EARLY_EXIT
+            s_alive[wave] = 1u;
+#endif
+        }
         __syncthreads();
-        if (threadIdx.x == 0) {
+#if RT_SHADE_EARLY_EXIT
+        // the block's leader is lane 0 of its first wave that is still alive
+        leader = lane == 0;
+        for (uint32_t w = 0; w < wave; w++) leader = leader && s_alive[w] == 0u;
+#endif
+        if (leader) {
             const uint32_t tot = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0];
             s_base[0] = tot ? atomicAdd(&ctl->n_active[itn], tot) : 0u;
         }
@@ -873,7 +914,7 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc
             s_cnt[wave][3] = cp;
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (leader) {
             uint32_t te = 0, tsd = 0, tp = 0, tv = 0;
             for (int w = 0; w < 4; w++) {
                 te += s_cnt[w][1];
