@@ -26,8 +26,8 @@
 // independent of how tiles are split over GPUs.
 #include "shading.h"
 
-#ifndef RT_SHADE_EARLY_EXIT
-#define RT_SHADE_EARLY_EXIT 1  // k_shade: waves with nothing to shade end before the block's barriers (0: they park)
+#ifndef RT_SHADE_LAST_WAVE
+#define RT_SHADE_LAST_WAVE 1  // k_shade (dealing instances): no barrier before the queue reservation, the block's last wave writes it
 #endif
 #ifndef RT_QUEUE_BY_KIND
 #define RT_QUEUE_BY_KIND 1  // k_shade queues a block's rays kind by kind (0: wave by wave)
@@ -844,12 +844,11 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc
     // then ends without pending light terms the slot is marked dead and skipped next bounce
     uint32_t os;
     bool leader = threadIdx.x == 0;
-#if RT_SHADE_EARLY_EXIT
     __shared__ uint32_t s_alive[4];
-#endif
+    __shared__ uint32_t s_done;            // waves of the block that have staged their rays
+    __shared__ uint32_t s_stage[4][3][64];  // [wave][kind][rank]: queue entries waiting for the block's reservation
     {   // one atomic per block: wave counts -> LDS -> block base -> per-lane slot
         const unsigned long long m = __ballot(a.will_shade);
-#if RT_SHADE_EARLY_EXIT
         // A wave without a vertex to shade -- escaped / fold-only / dead paths, which the dealing step gathers into
         // whole waves -- writes its film values, reports zero counts and ENDS instead of parking at the block's two
         // barrier pairs (a barrier waits only for the waves that are still alive).  Parked waves hold their 168
@@ -872,22 +871,18 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc
             __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the LDS writes have landed before the wave ends
             return;
         }
-#endif
         if (lane == 0) {
             s_cnt[wave][0] = (uint32_t)__popcll(m);
-#if RT_SHADE_EARLY_EXIT
             s_alive[wave] = 1u;
-#endif
         }
         __syncthreads();
-#if RT_SHADE_EARLY_EXIT
         // the block's leader is lane 0 of its first wave that is still alive
         leader = lane == 0;
         for (uint32_t w = 0; w < wave; w++) leader = leader && s_alive[w] == 0u;
-#endif
         if (leader) {
             const uint32_t tot = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0];
             s_base[0] = tot ? atomicAdd(&ctl->n_active[itn], tot) : 0u;
+            s_done = 0u;
         }
         __syncthreads();
         uint32_t off = s_base[0];
@@ -912,6 +907,51 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc
             s_cnt[wave][1] = ce;
             s_cnt[wave][2] = cs;
             s_cnt[wave][3] = cp;
+        }
+        // No barrier in front of the queue reservation (instances with class dealing): a wave stages its entries in LDS
+        // and ENDS; the block's last wave to arrive (an LDS counter) reserves the queue range and writes everybody's
+        // entries.  A wave that has finished shade_b no longer holds its registers until the block's slowest wave has:
+        // k_shade -2.3 % on C4 and C3; the Lambert-only instance (waves of equal length) loses 2 % and keeps the barrier.
+        if (RT_SHADE_LAST_WAVE && FEAT != 0) {
+            const unsigned long long below0 = (1ull << lane) - 1ull;
+            if (r.emit_ext) s_stage[wave][0][__popcll(me & below0)] = os | (kRayExt << 30);
+            if (r.emit_sh) s_stage[wave][1][__popcll(ms & below0)] = os | (kRayShadow << 30);
+            if (r.emit_pr) s_stage[wave][2][__popcll(mp & below0)] = os | (kRayProbe << 30);
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): staged before the wave is counted
+            uint32_t n_part = 0;
+            for (uint32_t w = 0; w < 4; w++) n_part += s_alive[w];
+            uint32_t prev = 0;
+            if (lane == 0) prev = atomicAdd(&s_done, 1u);
+            prev = (uint32_t)__builtin_amdgcn_readfirstlane((int)prev);
+            if (prev + 1u < n_part) return;
+            // last wave: totals, one reservation, all entries kind by kind ([ext of the waves][shadow ...][probe ...])
+            uint32_t cnt[3][4], tk[3] = {0, 0, 0}, tv = 0;
+            for (uint32_t w = 0; w < 4; w++) {
+                const bool al = s_alive[w] != 0u;
+                for (uint32_t k = 0; k < 3; k++) {
+                    cnt[k][w] = al ? s_cnt[w][1 + k] : 0u;
+                    tk[k] += cnt[k][w];
+                }
+                tv += s_cnt[w][0];
+            }
+            const uint32_t tot = tk[0] + tk[1] + tk[2];
+            uint32_t qb = 0;
+            if (lane == 0) {
+                qb = tot ? atomicAdd(&ctl->n_rays[itn], tot) : 0u;
+                DevStats* sh = stat_shard(stats);
+                if (tk[0]) atomicAdd(&sh->r1, (unsigned long long)tk[0]);
+                if (tk[1]) atomicAdd(&sh->r2, (unsigned long long)tk[1]);
+                if (tk[2]) atomicAdd(&sh->r3, (unsigned long long)tk[2]);
+                if (tv) atomicAdd(&sh->vertices, (unsigned long long)tv);
+            }
+            qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
+            uint32_t o = qb;
+            for (uint32_t k = 0; k < 3; k++)
+                for (uint32_t w = 0; w < 4; w++) {
+                    if (lane < cnt[k][w]) queue_out[o + lane] = s_stage[w][k][lane];
+                    o += cnt[k][w];
+                }
+            return;
         }
         __syncthreads();
         if (leader) {

@@ -1,11 +1,16 @@
 #!/bin/bash
-# PMC passes only (the kernel stats and bench lines of this state are already collected)
-for tag in c4 c3 c2; do
-  tools/prof_pmc.sh $tag --workload $tag > gpurun_out/pmc_$tag.log 2>&1
-  mkdir -p gpurun_out/refresh_$tag
-  cp gpurun_out/pmc_summary_$tag.json gpurun_out/refresh_$tag/pmc_summary.json
-  python3 tools/collect_profiles.py --stage $tag
-  cp profiles/trace_pmc_$tag.json gpurun_out/refresh_$tag/
-  python3 bench.py --workload $tag --no-extra > gpurun_out/refresh_$tag/bench_full.json 2> gpurun_out/refresh_$tag/bench_full.err
-  tail -c 150 gpurun_out/refresh_$tag/bench_full.json; echo
+python -m pytest tests -x -q -m gpu 2>&1 | tail -2
+run() { label=$1; wl=$2; shift 2
+  env "$@" timeout 900 python bench.py --workload $wl --no-cpu-baseline --no-extra --steps 3 --warmup 1 > gpurun_out/tmp.json 2>gpurun_out/tmp.err
+  python - "$label $wl" <<'PY'
+import json,sys
+try:
+    d=json.load(open('gpurun_out/tmp.json')); r=d['roofline']; k=r['kernels']['k_shade']
+    print('%-22s Mrays/s %.0f ms %.2f trace %.2f shade %.2f'%(sys.argv[1],d['value'],d['ms_per_step'],r['avg_launch_ms']*r['launches_per_step'],k['avg_launch_ms']*k['launches_per_step']))
+except Exception as e: print(sys.argv[1],'FAILED',e, open('gpurun_out/tmp.err').read()[-300:])
+PY
+}
+for wl in c4 c3 c2 hdr1 hdr c3p; do
+run "final" $wl X=1
 done
+run "final f32" c4 X=1 
