@@ -1,5 +1,6 @@
 #!/bin/bash
-python -m pytest tests -x -q -m gpu 2>&1 | tail -2
+V=$PWD/rustraytracer_amd/csrc/build/variants
+RT_AMD_LIB=$V/ol.so timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_arms.py -x -q -m gpu 2>&1 | tail -1
 run() { label=$1; wl=$2; shift 2
   env "$@" timeout 900 python bench.py --workload $wl --no-cpu-baseline --no-extra --steps 3 --warmup 1 > gpurun_out/tmp.json 2>gpurun_out/tmp.err
   python - "$label $wl" <<'PY'
@@ -10,7 +11,9 @@ try:
 except Exception as e: print(sys.argv[1],'FAILED',e, open('gpurun_out/tmp.err').read()[-300:])
 PY
 }
-for wl in c4 c3 c2 hdr1 hdr c3p; do
-run "final" $wl X=1
+for wl in c4 c3; do
+run "base" $wl X=1
+run "other last" $wl RT_AMD_LIB=$V/ol.so
+run "other last, 6 cls" $wl RT_AMD_LIB=$V/ol6.so
+run "6 classes" $wl RT_AMD_LIB=$V/c6.so
 done
-run "final f32" c4 X=1 
