@@ -205,15 +205,39 @@ def roofline(b, acc, stc, steps):
     avg_launch_s = (acc["trace_ms"] / 1e3) / max(acc["launches"], 1)
     bytes_per_launch = alg / max(launches_per_step, 1)
     achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-    traffic = traffic_step = frac_pmc = None
+    # Counter figures come from a committed rocprofv3 --pmc profile (counters cannot be read inside this run); the
+    # profile names the kernel build it was taken from, and the figure is WITHHELD (null, with the reason in
+    # traffic_source.stale) when the k_trace machine code of the library running now hashes differently.
+    traffic = traffic_step = frac_pmc = frac_step = None
+    source = None
     pmc = os.path.join(ROOT, "profiles", f"trace_pmc_{b.name}.json")
-    if b.world == 1 and os.path.exists(pmc):
+    if b.world == 1 and b.precision == 0 and os.path.exists(pmc):
         try:
-            traffic = float(json.load(open(pmc)).get("hbm_bytes_per_launch"))
-            traffic_step = traffic * launches_per_step
-            frac_pmc = traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS
-        except Exception:
-            traffic = traffic_step = frac_pmc = None
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from kernel_hash import kernel_hash
+            rec = json.load(open(pmc))
+            now = kernel_hash("k_trace")
+            prof_hash = (rec.get("kernel_object_hash") or {}).get("sha256")
+            source = {"file": os.path.relpath(pmc, ROOT), "commit": rec.get("commit"),
+                      "kernel_object_hash": prof_hash, "running_kernel_object_hash": now and now["sha256"],
+                      "stale": None}
+            if prof_hash is None:
+                source["stale"] = "the profile predates kernel hashing (round 2): figure kept, build unverified"
+            elif now is None or now["sha256"] != prof_hash:
+                source["stale"] = "k_trace was rebuilt since the profile was taken: counter figures withheld"
+            if source["stale"] is None or prof_hash is None:
+                traffic = float(rec.get("hbm_bytes_per_launch"))
+                traffic_step = traffic * launches_per_step
+                frac_pmc = traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS
+                # all kernels of a step (trace + shade + generate + resolve + tail): HBM bytes per step / ms_per_step
+                all_k = rec.get("hbm_bytes_per_step_all_kernels")
+                whole_lib_same = rec.get("library_kernels_hash") == kernel_hash("k_")
+                if all_k and whole_lib_same:
+                    frac_step = float(all_k) / (acc["dt"] / max(steps, 1)) / 1e9 / HBM_PEAK_GBS
+                    source["hbm_bytes_per_step_all_kernels"] = float(all_k)
+        except Exception as e:  # a malformed profile must not take the bench line down
+            traffic = traffic_step = frac_pmc = frac_step = None
+            source = {"file": os.path.relpath(pmc, ROOT), "stale": f"unreadable: {e}"}
     sh_alg = SHADE_BYTES_PER_VERTEX * stc.vertices_shaded
     sh_launches_per_step = acc["shade_launches"] / max(steps, 1)
     sh_avg_s = (acc["shade_ms"] / 1e3) / max(acc["shade_launches"], 1)
@@ -223,6 +247,7 @@ def roofline(b, acc, stc, steps):
             "kernel": "k_trace", "avg_launch_ms": avg_launch_s * 1e3, "launches_per_step": launches_per_step,
             "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_bytes_per_step": alg,
             "traffic_per_step": traffic_step, "hbm_frac_rocprof": frac_pmc,
+            "hbm_frac_rocprof_step": frac_step, "traffic_source": source,
             "bytes_per_ray": alg / max(trace_rays, 1),
             "nodes_per_ray": (stc.nodes_fetched - stc.tail_nodes_fetched) / max(trace_rays, 1),
             "tris_per_ray": (stc.tris_tested - stc.tail_tris_tested) / max(trace_rays, 1),
@@ -275,6 +300,13 @@ def main():
         else:
             dist.init_process_group(backend="gloo")
     coll_dev = "cuda" if args.backend == "nccl" else "cpu"
+    # N ranks commit the same scene: the host BVH is built once per node and shared through /dev/shm (abi.hip:
+    # build_bvh_shared) instead of N simultaneous 16-thread SAH builds; rank 0 removes the files at the end
+    cache_dir = None
+    if world > 1 and "RT_BVH_CACHE" not in os.environ:
+        cache_dir = f"/dev/shm/rt_bvh_cache_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}"
+        os.makedirs(cache_dir, exist_ok=True)
+        os.environ["RT_BVH_CACHE"] = cache_dir
 
     def barrier():
         if world > 1:
@@ -291,6 +323,12 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(rr_, op=dist.ReduceOp.SUM)
     dt_max, gather_max, rays_all = float(tt[0].item()), float(tt[1].item()), float(rr_.item())
+    devices_all = None
+    if world > 1:  # which physical device every rank used (rank 0 reports the list)
+        dv = torch.zeros(world, dtype=torch.int64, device=coll_dev)
+        dv[rank] = local_rank
+        dist.all_reduce(dv, op=dist.ReduceOp.SUM)
+        devices_all = [int(x) for x in dv.tolist()]
     stc = b.counted()
 
     if rank == 0:
@@ -305,10 +343,15 @@ def main():
                        "width": W, "height": H, "spp": spp, "max_depth": rr.MAX_DEPTH, "seed": 0,
                        "triangles": b.info["n_triangles"], "bvh_nodes": b.info["n_bvh_nodes"],
                        "rays_per_step": rays_all / args.steps, "paths_per_step": W * H * spp,
-                       "parallelism": f"tiles{world}"},
+                       "parallelism": f"tiles{world}", "bvh_from_shared_cache": bool(b.info.get("build_from_cache", 0)),
+                       "scene_commit_ms": b.info.get("build_ms")},
             "roofline": roofline(b, acc, stc, args.steps),
             "device_ms_per_step": acc["kernel_ms"] / args.steps,
             "gather_ms_per_step": gather_max / args.steps * 1e3 if world > 1 else 0.0,
+            # what the collective layer actually saw (N > 1): backend as torch reports it ("nccl" = RCCL on ROCm) and the
+            # number of ranks in the group, plus the devices the ranks rendered on
+            "rccl_ranks": ({"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                            "devices": devices_all} if world > 1 else None),
             # also paths/s and the mean path length (rays per camera sample), whole job
             "mpaths_per_s": W * H * spp * args.steps / dt_max / 1e6,
             "mean_rays_per_path": rays_all / args.steps / (W * H * spp),
@@ -326,7 +369,7 @@ def main():
             rf = roofline(e, ea, ec, esteps)
             extra.append({"workload": e.desc, "value": ea["rays"] / ea["dt"] / 1e6, "unit": "Mrays/s",
                           "ms_per_step": ea["dt"] / esteps * 1e3, "steps": esteps,
-                          "roofline": {k: rf[k] for k in ("achieved", "frac", "traffic", "hbm_frac_rocprof",
+                          "roofline": {k: rf[k] for k in ("achieved", "frac", "traffic", "hbm_frac_rocprof", "hbm_frac_rocprof_step", "traffic_source",
                                                           "avg_launch_ms", "launches_per_step", "bytes_per_ray")},
                           "k_shade_ms_per_step": ea["shade_ms"] / esteps, "k_trace_ms_per_step": ea["trace_ms"] / esteps})
             e.close()
@@ -355,6 +398,10 @@ def main():
         print(json.dumps(out), flush=True)
     b_main.close()
     if world > 1:
+        dist.barrier()
+        if rank == 0 and cache_dir:
+            import shutil
+            shutil.rmtree(cache_dir, ignore_errors=True)
         dist.destroy_process_group()
 
 

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2
+#define RT_ABI_VERSION 3
 
 /* ---------------------------------------------------------------- status */
 typedef enum rt_status {
@@ -364,6 +364,9 @@ typedef struct rt_scene_info {
     uint64_t build_flags;    /* RT_COMMIT_* the scene was committed with          */
     double build_ms;         /* BVH build + leaf layout + their upload, host clock */
     double build_device_ms;  /* RT_COMMIT_DEVICE_LBVH: device time of the build   */
+    uint64_t build_from_cache; /* (ABI 3) 1: the host tree was read from the node-local cache
+                                  another process published (environment RT_BVH_CACHE=<dir>:
+                                  the ranks of one node build a scene's tree once)          */
 } rt_scene_info;
 int rt_scene_get_info(const rt_scene* s, rt_scene_info* out);
 

@@ -134,7 +134,8 @@ class rt_scene_info(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in (
         "n_prims", "n_triangles", "n_others", "n_bvh_nodes", "bvh_depth", "node_bytes", "tri_bytes",
         "other_bytes", "device_bytes_total", "build_flags")] + [("build_ms", C.c_double),
-                                                                     ("build_device_ms", C.c_double)]
+                                                                     ("build_device_ms", C.c_double),
+                                                                     ("build_from_cache", C.c_uint64)]
 
 
 # every symbol include/rt_abi.h and include/rt_host.h declare

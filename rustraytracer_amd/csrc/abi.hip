@@ -16,6 +16,10 @@
 #include <thread>
 #include <vector>
 
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
+
 #include "bvh_build.h"
 #include "bvh_gpu.h"
 #include "env_dist.h"
@@ -466,6 +470,94 @@ __global__ __launch_bounds__(256) void k_make_leaf_trav(const double* __restrict
 
 static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cache);
 
+// ---- host BVH shared between the processes of one node (RT_BVH_CACHE=<directory>, e.g. /dev/shm/...)
+// bench.py --gpus N runs one process per GPU and every rank commits the same scene: without this, eight ranks each
+// run the 16-thread SAH build of 1.74 M primitives at the same time on the same host cores.  With the variable set,
+// the ranks take an exclusive flock() on <dir>/rtbvh_<key>.lock in turn: the first one builds and publishes
+// <dir>/rtbvh_<key>.bin (write to a temporary name, then rename), the others read it.  The key hashes everything
+// build_bvh() looks at -- the primitive records incl. their f64 boxes -- and a format tag; a file that fails any
+// check is ignored and rebuilt.  Results cannot depend on it: the tree only culls (geom.h), and the file holds
+// exactly what build_bvh() returned.
+struct BvhCacheHeader {
+    char magic[8];  // "RTBVH\0\0\1"
+    uint64_t key, n_prims, n_nodes;
+    uint32_t depth, node_bytes;
+};
+static uint64_t bvh_cache_key(const rt_primitive* prims, size_t n) {
+    uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)sizeof(DevNode) ^ ((uint64_t)kLeafTargetPrims << 32);
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(prims);
+    const size_t bytes = n * sizeof(rt_primitive);
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) {  // FNV-1a over 64-bit words (the records are a multiple of 8 bytes)
+        uint64_t w;
+        std::memcpy(&w, b + i, 8);
+        h = (h ^ w) * 0x100000001b3ull;
+        h ^= h >> 29;
+    }
+    for (; i < bytes; i++) h = (h ^ b[i]) * 0x100000001b3ull;
+    return h ^ (uint64_t)n;
+}
+static bool bvh_cache_load(const std::string& path, uint64_t key, size_t np, BvhOut& out) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    BvhCacheHeader hd;
+    bool ok = fread(&hd, sizeof(hd), 1, f) == 1 && std::memcmp(hd.magic, "RTBVH\0\0\1", 8) == 0 && hd.key == key &&
+              hd.n_prims == np && hd.node_bytes == sizeof(DevNode) && hd.n_nodes > 0 && hd.n_nodes <= 2 * np + 2;
+    if (ok) {
+        out.nodes.resize(hd.n_nodes);
+        out.order.resize(np);
+        out.depth = hd.depth;
+        ok = fread(out.nodes.data(), sizeof(DevNode), hd.n_nodes, f) == hd.n_nodes &&
+             fread(out.order.data(), sizeof(uint32_t), np, f) == np;
+        for (size_t i = 0; ok && i < np; i++) ok = out.order[i] < np;  // a permutation entry out of range: damaged file
+    }
+    fclose(f);
+    return ok;
+}
+static void bvh_cache_store(const std::string& path, uint64_t key, size_t np, const BvhOut& bvh) {
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return;
+    BvhCacheHeader hd{};
+    std::memcpy(hd.magic, "RTBVH\0\0\1", 8);
+    hd.key = key;
+    hd.n_prims = np;
+    hd.n_nodes = bvh.nodes.size();
+    hd.depth = bvh.depth;
+    hd.node_bytes = sizeof(DevNode);
+    const bool ok = fwrite(&hd, sizeof(hd), 1, f) == 1 &&
+                    fwrite(bvh.nodes.data(), sizeof(DevNode), bvh.nodes.size(), f) == bvh.nodes.size() &&
+                    fwrite(bvh.order.data(), sizeof(uint32_t), np, f) == np;
+    if (fclose(f) != 0 || !ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());
+}
+// build_bvh() once per node: returns 1 when the tree came from the cache, 0 when this process built it
+static int build_bvh_shared(const rt_primitive* prims, size_t np, BvhOut& bvh) {
+    const char* dir = getenv("RT_BVH_CACHE");
+    if (!dir || !*dir || np < 4096) {  // small scenes build in milliseconds
+        build_bvh(prims, np, bvh);
+        return 0;
+    }
+    const uint64_t key = bvh_cache_key(prims, np);
+    char name[64];
+    snprintf(name, sizeof(name), "/rtbvh_%016llx", (unsigned long long)key);
+    const std::string base = std::string(dir) + name;
+    const int lock = open((base + ".lock").c_str(), O_CREAT | O_RDWR, 0600);
+    if (lock >= 0) (void)flock(lock, LOCK_EX);  // (no lock, e.g. a read-only directory: everybody builds, as before)
+    int from_cache = 0;
+    if (bvh_cache_load(base + ".bin", key, np, bvh)) {
+        from_cache = 1;
+    } else {
+        bvh = BvhOut{};
+        build_bvh(prims, np, bvh);
+        if (lock >= 0) bvh_cache_store(base + ".bin", key, np, bvh);
+    }
+    if (lock >= 0) {
+        (void)flock(lock, LOCK_UN);
+        close(lock);
+    }
+    return from_cache;
+}
+
 // The builder emits nodes depth-first.  Move the top of the tree -- the first `n_top` nodes met breadth-first from the
 // root, which every ray walks -- to the front, in that order: they then share a few cache lines, and a kernel can hold
 // them on chip (k_trace's RT_LDS_NODES experiment).  Pure renumbering: the tree and every box stay what they were.
@@ -506,10 +598,23 @@ int rt_scene_commit_ex(rt_scene* s, uint32_t flags) {
     int rc = validate_scene(s);
     if (rc != RT_OK) return rc;
     HostLeafData cache;
-    if ((rc = commit_to(s, s, flags, cache)) != RT_OK) return rc;
+    rc = commit_to(s, s, flags, cache);
     // multi-device context: the scene is replicated on every device, same arrays, same tree
-    for (rt_scene* r : s->replicas)
-        if ((rc = commit_to(s, r, flags, cache)) != RT_OK) return rc;
+    for (size_t i = 0; rc == RT_OK && i < s->replicas.size(); i++) rc = commit_to(s, s->replicas[i], flags, cache);
+    if (rc != RT_OK) {
+        // a copy that failed half way (e.g. out of memory on one peer) must not leave the scene renderable: every
+        // device copy made so far is released and the scene stays mutable, so the caller may retry or destroy it
+        auto release = [](rt_scene* t) {
+            (void)hipSetDevice(t->ctx->device);
+            for (void* p : t->allocs) (void)hipFree(p);
+            t->allocs.clear();
+            t->dev = DevScene{};
+            t->committed = false;
+        };
+        release(s);
+        for (rt_scene* r : s->replicas) release(r);
+        return rc;
+    }
     return RT_OK;
 }
 
@@ -624,7 +729,7 @@ static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cac
     } else {
         if (!cache.valid) {
         BvhOut bvh;
-        build_bvh(s->prims.data(), s->prims.size(), bvh);
+        t->info.build_from_cache = (uint32_t)build_bvh_shared(s->prims.data(), s->prims.size(), bvh);
         if (bvh.depth + 1 > (uint32_t)kMaxBvhDepth) return fail(RT_ERR_UNSUPPORTED, "BVH depth %u exceeds the traversal stack", bvh.depth);
         // leaf-ordered triangle vertices + ids
         std::vector<uint32_t>& leaf_prim = cache.leaf_prim;
@@ -1029,6 +1134,19 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
     const uint32_t pass_spp = s_end - s_first;
     HIP_TRY(hipMemsetAsync(c->stats, 0, sizeof(DevStats) * kStatShards, stream));
     const size_t NP = pix.size();
+    if (NP > 0) {
+        // The device copy of the pixel list is refreshed whenever this rank owns pixels -- also for an empty progressive
+        // pass (sample_first >= spp): a multi-device context's gather packs every peer's film through it (render_multi).
+        if (c->pix_capacity < NP) {
+            if (c->pix_list) HIP_TRY(hipFree(c->pix_list));
+            c->pix_list = nullptr;
+            c->pix_capacity = 0;
+            HIP_TRY(hipMalloc((void**)&c->pix_list, NP * sizeof(uint32_t)));
+            c->pix_capacity = NP;
+        }
+        // (pix is a local: the copy has to finish before it goes out of scope on the early-return paths)
+        HIP_TRY(hipMemcpyAsync(c->pix_list, c->last_pix.data(), NP * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    }
     double kernel_ms = 0.0, trace_ms = 0.0, shade_ms = 0.0;
     uint64_t trace_launches = 0, shade_launches = 0;
     if (NP > 0 && pass_spp > 0) {
@@ -1067,13 +1185,6 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
             c->lf[2] = c->lf[1] + batch_cap;
             c->lf_capacity = batch_cap;
         }
-        if (c->pix_capacity < NP) {
-            if (c->pix_list) HIP_TRY(hipFree(c->pix_list));
-            c->pix_list = nullptr;
-            HIP_TRY(hipMalloc((void**)&c->pix_list, NP * sizeof(uint32_t)));
-            c->pix_capacity = NP;
-        }
-        HIP_TRY(hipMemcpyAsync(c->pix_list, pix.data(), NP * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         RenderJob job;
         job.c = c;
         job.s = s;
@@ -1301,6 +1412,9 @@ static int render_multi(rt_context* c, rt_scene* s, const rt_camera* cam, const 
             cfgs[i].tile_rank = (uint32_t)i;
         }
     int rc = RT_OK;
+    if (s->replicas.size() != c->peers.size()) return fail(RT_ERR_STATE, "rt_render: scene was not created on this multi-device context");
+    for (const rt_scene* r : s->replicas)
+        if (!r->committed) return fail(RT_ERR_STATE, "rt_render: a device copy of the scene is not committed");
     for (int i = 1; i < N; i++) {
         rt_context* p = c->peers[i - 1];
         if (p->pf_cap < npix) {  // scratch film of the peer

@@ -868,7 +868,7 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc
                 s_cnt[wave][3] = 0u;
                 s_alive[wave] = 0u;
             }
-            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the LDS writes have landed before the wave ends
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");  // the LDS writes have landed before the wave ends
             return;
         }
         if (lane == 0) {
@@ -917,12 +917,16 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc
             if (r.emit_ext) s_stage[wave][0][__popcll(me & below0)] = os | (kRayExt << 30);
             if (r.emit_sh) s_stage[wave][1][__popcll(ms & below0)] = os | (kRayShadow << 30);
             if (r.emit_pr) s_stage[wave][2][__popcll(mp & below0)] = os | (kRayProbe << 30);
-            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): staged before the wave is counted
             uint32_t n_part = 0;
             for (uint32_t w = 0; w < 4; w++) n_part += s_alive[w];
+            // release (every lane: all of them staged entries): this wave's s_stage / s_cnt writes are visible before it is
+            // counted; acquire: the last arriver reads the other waves' entries only after it has seen their counts.
+            // Workgroup scope, LDS address space only -- the wave's global stores need not have landed.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             uint32_t prev = 0;
-            if (lane == 0) prev = atomicAdd(&s_done, 1u);
+            if (lane == 0) prev = __hip_atomic_fetch_add(&s_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             prev = (uint32_t)__builtin_amdgcn_readfirstlane((int)prev);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
             if (prev + 1u < n_part) return;
             // last wave: totals, one reservation, all entries kind by kind ([ext of the waves][shadow ...][probe ...])
             uint32_t cnt[3][4], tk[3] = {0, 0, 0}, tv = 0;

@@ -24,3 +24,27 @@ def test_ranks_on_one_gpu_gather_the_one_rank_film(ranks):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["ranks"] == ranks and rec["bit_identical"] and rec["rays_sum"] == rec["rays_one_rank"]
+
+
+def _gpu_count():
+    # torch.cuda.device_count() does not initialise the GPU in this process (it reads the driver's device list)
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 4, 8])
+def test_ranks_on_distinct_gpus_gather_over_rccl(ranks):
+    """Arms itself on a multi-GPU box: one fresh process per GPU, backend nccl (= RCCL over xGMI), FilmGather on device
+    tensors -- the path bench.py --gpus N takes (render.rs:49-71's tile farm).  Skipped on a one-GPU box."""
+    if _gpu_count() < ranks:
+        pytest.skip(f"needs {ranks} GPUs, this box has {_gpu_count()}")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(29700 + 13 * ranks),
+           os.path.join(ROOT, "tools", "mp_film_check.py"), "--backend", "nccl"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["ranks"] == ranks and rec["backend"] == "nccl" and rec["bit_identical"]
+    assert rec["rays_sum"] == rec["rays_one_rank"]

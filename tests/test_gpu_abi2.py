@@ -13,8 +13,18 @@ from rustraytracer_amd import _ffi as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("ids", [(0, 0), (0, 0, 0)], ids=["2ctx", "3ctx"])
+def _need_gpus(ids):
+    import torch
+    have = torch.cuda.device_count()
+    if max(ids) >= have:
+        pytest.skip(f"needs {max(ids) + 1} GPUs, this box has {have}")
+
+
+# (0, 1) and (0, 1, 2, 3): DISTINCT devices -- hipDeviceEnablePeerAccess, hipMemcpyPeerAsync between two GPUs and the
+# cross-device hipStreamWaitEvent of render_multi; they arm themselves on a multi-GPU box and skip on a one-GPU box
+@pytest.mark.parametrize("ids", [(0, 0), (0, 0, 0), (0, 1), (0, 1, 2, 3)], ids=["2ctx", "3ctx", "gpu01", "gpu0123"])
 def test_multi_device_context_is_bit_identical(gpu_ctx, ids):
+    _need_gpus(ids)
     """rt_context_create(device_ids, n > 1) (SURVEY.md 8b): one host thread per device, scene replicated at commit,
     tiles interleaved, peers' pixels packed + copied peer-to-peer + scattered into the caller's film.  A one-GPU box
     exercises it with the same device id repeated (each entry gets its own context, streams and pools)."""
@@ -50,6 +60,34 @@ def test_multi_device_context_is_bit_identical(gpu_ctx, ids):
     for g in (gsd, gsm, gs1):
         g.close()
     mc.close()
+
+
+def test_multi_device_empty_progressive_pass(gpu_ctx):
+    """A progressive pass past the last sample (sample_first >= next_pow2(spp)) renders nothing; on a multi-device
+    context the gather still runs over every peer's pixel list, which therefore has to be this render's list even
+    though no kernel of the pass used it (a fresh peer had none, a reused one a stale list of another
+    image size).  The caller's film must come back unchanged."""
+    sc = rr.cornell_box()
+    mc = rr.Context([0, 0, 0])
+    gsm = mc.upload(sc)
+    # a first render of ANOTHER size leaves a longer pixel list on the peers
+    mc.render(gsm, sc.camera, rr.make_cfg(96, 80, 2, seed=1))
+    cfg = rr.make_cfg(48, 32, 4, seed=1)
+    r1, n1, _ = mc.render(gsm, sc.camera, cfg)
+    film = (r1.copy(), n1.copy())
+    _, _, st = mc.render(gsm, sc.camera, rr.make_cfg(48, 32, 4, seed=1, sample_first=4, sample_count=2, accumulate=True),
+                         film=film)
+    assert st.paths == 0 and st.rays == 0
+    assert np.array_equal(film[0], r1) and np.array_equal(film[1], n1)
+    # ... also as the very first call on a fresh multi-device context (peers without any pixel list yet)
+    mc2 = rr.Context([0, 0])
+    gs2 = mc2.upload(sc)
+    film2 = (r1.copy(), n1.copy())
+    mc2.render(gs2, sc.camera, rr.make_cfg(48, 32, 4, seed=1, sample_first=8, accumulate=True), film=film2)
+    assert np.array_equal(film2[0], r1) and np.array_equal(film2[1], n1)
+    for g, c in ((gs2, mc2), (gsm, mc)):
+        g.close()
+        c.close()
 
 
 def test_multi_device_render_device_film(gpu_ctx):
@@ -275,3 +313,44 @@ def test_render_traversal_kernel_on_caller_rays(gpu_ctx, name):
     gd.close()
     gs.close()
     osc.close()
+
+
+def test_host_bvh_is_shared_through_the_node_local_cache(gpu_ctx, tmp_path, monkeypatch):
+    """RT_BVH_CACHE=<dir> (abi.hip: build_bvh_shared): the first process to commit a scene publishes the host-built
+    tree, later commits of the same primitives read it (bench.py --gpus N: eight ranks build once, not eight times).
+    Same film either way; a damaged or foreign file is ignored and rebuilt."""
+    import glob
+    import os
+    sc = rr.cornell_box_statue(mesh_faces=9000, variant=1)
+    cfg = rr.make_cfg(48, 40, 4, seed=6)
+    g0 = gpu_ctx.upload(sc)
+    assert g0.info()["build_from_cache"] == 0
+    base = gpu_ctx.render(g0, sc.camera, cfg)
+    g0.close()
+    monkeypatch.setenv("RT_BVH_CACHE", str(tmp_path))
+    g1 = gpu_ctx.upload(sc)
+    assert g1.info()["build_from_cache"] == 0
+    files = glob.glob(str(tmp_path / "rtbvh_*.bin"))
+    assert len(files) == 1 and os.path.getsize(files[0]) > 9000 * 4
+    g2 = gpu_ctx.upload(sc)
+    assert g2.info()["build_from_cache"] == 1 and g2.info()["n_bvh_nodes"] == g1.info()["n_bvh_nodes"]
+    for g in (g1, g2):
+        r, n, s = gpu_ctx.render(g, sc.camera, cfg)
+        assert np.array_equal(r, base[0]) and np.array_equal(n, base[1]) and s.rays == base[2].rays
+        g.close()
+    # another scene gets another key; a truncated file is rejected
+    sc2 = rr.cornell_box_statue(mesh_faces=9001, variant=1)
+    g3 = gpu_ctx.upload(sc2)
+    assert g3.info()["build_from_cache"] == 0 and len(glob.glob(str(tmp_path / "rtbvh_*.bin"))) == 2
+    g3.close()
+    with open(files[0], "r+b") as fh:
+        fh.truncate(os.path.getsize(files[0]) // 2)
+    g4 = gpu_ctx.upload(sc)
+    assert g4.info()["build_from_cache"] == 0
+    r, n, _ = gpu_ctx.render(g4, sc.camera, cfg)
+    assert np.array_equal(r, base[0])
+    g4.close()
+    # the device builder does not use it
+    g5 = gpu_ctx.upload(sc, device_build=True)
+    assert g5.info()["build_from_cache"] == 0
+    g5.close()

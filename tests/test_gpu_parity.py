@@ -143,6 +143,50 @@ def test_render_matches_oracle(gpu_ctx, case):
     gs.close()
 
 
+def lens_camera(frm, to, aspect, vfov, aperture, focus):
+    """Camera::new (geometry.rs:110-175) with aperture > 0: the lens arm of Camera::get_ray (geometry.rs:177-190)."""
+    import ctypes as C
+    cam = F.rt_camera()
+    rc = F.lib().rrh_camera_new(O.vec(*frm), O.vec(*to), O.vec(0, 1, 0), aspect, vfov, aperture, focus, 0.0, 1.0, C.byref(cam))
+    assert rc == 0 and cam.lens_radius == aperture / 2
+    return cam
+
+
+LENS_CASES = [
+    # make_world's camera (scenes.rs:16-24: aperture 0.16, focus 10) on the sphere preset, and a wide lens focused on
+    # the back of the Cornell box; a third case on a mesh scene with a 2-rank tile split
+    ("sphere_roughness_ap0.16", lambda: rr.sphere_roughness(16 / 9), (13.0, 2.0, 3.0), (0.0, 0.0, 0.0), 16 / 9, 20.0, 0.16, 10.0, 64, 36, 8, 1),
+    ("cornell_box_ap30", lambda: rr.cornell_box(), (278.0, 278.0, -800.0), (278.0, 278.0, 0.0), 1.0, 40.0, 30.0, 800.0, 64, 64, 16, 1),
+    ("two_dragons_ap0.5", lambda: rr.two_dragons(1920 / 1080, mesh_faces=6000, variant=0), (0.0, 4.0, 12.0), (2.0, 1.0, 0.0), 1920 / 1080, 60.0, 0.5, 12.0, 64, 36, 8, 2),
+]
+
+
+@pytest.mark.parametrize("case", LENS_CASES, ids=[c[0] for c in LENS_CASES])
+def test_lens_camera_matches_oracle(gpu_ctx, case):
+    """aperture > 0: k_generate's rejection loop (util.rs:105-113) must consume exactly the oracle's draws -- one pair
+    more or less would shift every later draw of the path.  Films, counts and ray counters bit for bit."""
+    name, make, frm, to, aspect, vfov, aperture, focus, W, H, spp, world = case
+    sc = make()
+    cam = lens_camera(frm, to, aspect, vfov, aperture, focus)
+    osc = O.OracleScene(sc)
+    gs = gpu_ctx.upload(sc)
+    cfg = rr.make_cfg(W, H, spp, seed=17)
+    ro, no, so = osc.render(cam, cfg, O.ORDERED)
+    pin, _, _ = osc.render(sc.camera if aperture == 0 else lens_camera(frm, to, aspect, vfov, 0.0, focus), cfg, O.ORDERED)
+    assert not np.array_equal(pin, ro)  # the lens arm is live
+    acc, nacc, rays = np.zeros_like(ro), np.zeros_like(no), np.zeros(4, dtype=np.int64)
+    for rank in range(world):
+        r, n, s = gpu_ctx.render(gs, cam, rr.make_cfg(W, H, spp, seed=17, tile_rank=rank, tile_world=world))
+        acc += r
+        nacc += n
+        rays += np.array([s.rays_extension, s.rays_shadow, s.rays_probe, s.vertices_shaded])
+    assert np.array_equal(nacc, no)
+    assert rmse(np.nan_to_num(acc), nacc, np.nan_to_num(ro), no) < RMSE_TOL
+    assert np.array_equal(acc, ro, equal_nan=True)
+    assert tuple(rays) == (so.rays_extension, so.rays_shadow, so.rays_probe, so.vertices_shaded)
+    gs.close()
+
+
 def test_render_reference_shaped_oracle(gpu_ctx):
     """Same image against the reference-shaped exhaustive traversal (hittable.rs:591-634)."""
     sc = rr.cornell_box_statue(mesh_faces=3000, variant=1)

@@ -73,7 +73,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(F.ABI_SYMBOLS) | set(F.HOST_SYMBOLS), declared ^ (set(F.ABI_SYMBOLS) | set(F.HOST_SYMBOLS))
     for name in sorted(declared):
         assert hasattr(L, name), name
-    assert L.rt_abi_version() == 2
+    assert L.rt_abi_version() == 3
     # the shared object really contains gfx950 code
     blob = open(F.LIB_PATH, "rb").read()
     assert b"amdgcn-amd-amdhsa--gfx950" in blob

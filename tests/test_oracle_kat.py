@@ -536,3 +536,76 @@ def test_oracle_regression_films(name):
     rgb, counts = mod.render(name)
     assert np.array_equal(counts, gold[name + "_counts"])
     assert np.array_equal(rgb, gold[name + "_rgb"], equal_nan=True)
+
+
+def _rng_draws(seed, pixel, sample, n):
+    out = (C.c_double * n)()
+    O.lib().oracle_rng_draws(seed, pixel, sample, n, out)
+    return list(out)
+
+
+def test_camera_lens_arm_draw_count_and_ray():
+    """Camera::get_ray with lens_radius > 0 (geometry.rs:177-190) on the (seed, pixel, sample) stream:
+    draws 0, 1 = film jitter, 2..4 = time + lens of get_camera_sample (sampler.rs:606-613, drawn, never read),
+    then util::rand_in_disk's rejection loop (util.rs:105-113: pairs until x*x + y*y < 1, both in [0, 1)),
+    then rand_range(t0, t1).  The camera ray is recomputed here with numpy from the raw draws; the FIRST draw after
+    the camera is pinned through the next thing that reads one: the light point of the first vertex's shadow ray
+    (Primitive::sample on the xz emitter, primitive.rs:438-476: x = x0 + u0 (x1 - x0)).  A loop that consumed one
+    pair more or less would move both."""
+    sc = rr.cornell_box()
+    osc = O.OracleScene(sc)
+    cam = F.rt_camera()
+    rc = F.lib().rrh_camera_new(O.vec(278, 278, -800), O.vec(278, 278, 0), O.vec(0, 1, 0), 1.0, 40.0, 30.0, 800.0, 0.0, 1.0,
+                                C.byref(cam))
+    assert rc == 0 and cam.lens_radius == 15.0
+    W = H = 32
+    cfg = rr.make_cfg(W, H, 4, seed=11)
+    a3 = lambda f: np.array(list(f))
+    origin, ulc, ho, vo = a3(cam.origin), a3(cam.upper_left_corner), a3(cam.horizontal_offset), a3(cam.vertical_offset)
+    cu, cv = a3(cam.u), a3(cam.v)
+    light = [p for p in sc.desc.contents.prims[: sc.desc.contents.n_prims] if p.light_index >= 0][0]
+    x0, x1 = light.v[0], light.v[2]
+    loops = []
+    checked_light = 0
+    for py in range(8, 24, 3):
+        for px in range(8, 24, 3):
+            for s in range(4):
+                d = _rng_draws(cfg.seed, py * W + px, s, 64)
+                k = 5
+                while True:
+                    dx, dy = d[k], d[k + 1]
+                    k += 2
+                    if dx * dx + dy * dy < 1.0:
+                        break
+                loops.append((k - 5) // 2)
+                k += 1  # rand_range(t0, t1)
+                u, v = (px + d[0]) / W, (py + d[1]) / H
+                in_disk = np.array([dx, dy, 0.0]) * cam.lens_radius
+                offset = cu * in_disk[0] + cv * in_disk[1]
+                to = ulc + ho * u - vo * v
+                ro, rd, tmin, t, prim = osc.sample_rays(cam, cfg, px, py, s)
+                assert np.array_equal(ro[0], origin + offset) and np.array_equal(rd[0], (to - origin) - offset)
+                # first vertex on a Lambertian wall: pick, ul0, ul1, us0, us1 follow (integrator.rs:530-548); ray 1 is the
+                # shadow ray towards the sampled light point when the light-sample term is non-black
+                if len(prim) > 1 and prim[0] >= 0 and tmin[1] == 0.0:
+                    sp = ro[1] + rd[1] * (1.0 - F.RT_SMALL)  # origin was moved by d * SMALL (hittable.rs:25-32)
+                    assert abs(sp[0] - (x0 + d[k + 1] * (x1 - x0))) < 1e-6
+                    checked_light += 1
+    assert max(loops) >= 2 and loops.count(1) > len(loops) // 2  # P(accept) = pi / 4
+    assert checked_light > 50
+
+
+def test_lens_camera_changes_only_the_camera_ray_statistics():
+    """aperture > 0 blurs but keeps energy: the image mean of the Cornell box stays within Monte-Carlo noise of the
+    pinhole render, and the film differs (the lens arm is live in oracle_render)."""
+    sc = rr.cornell_box()
+    osc = O.OracleScene(sc)
+    cam = F.rt_camera()
+    F.lib().rrh_camera_new(O.vec(278, 278, -800), O.vec(278, 278, 0), O.vec(0, 1, 0), 1.0, 40.0, 30.0, 800.0, 0.0, 1.0,
+                           C.byref(cam))
+    cfg = rr.make_cfg(48, 48, 16, seed=5)
+    r0, n0, _ = osc.render(sc.camera, cfg)
+    r1, n1, _ = osc.render(cam, cfg)
+    assert np.array_equal(n0, n1) and not np.array_equal(r0, r1)
+    m0, m1 = (r0 / n0[..., None]).mean(), (r1 / n1[..., None]).mean()
+    assert abs(m0 - m1) / m0 < 0.08

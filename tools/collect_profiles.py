@@ -22,7 +22,26 @@ def stage(tag):
     n = t["calls"]
     rd_raw = t["FETCH_SIZE"] * 1024 / n
     wr = t["WRITE_SIZE"] * 1024 / n
+    # every kernel of the profiled step: HBM bytes of the whole step (bench.py: roofline.hbm_frac_rocprof_step)
+    step_rd = sum(v.get("FETCH_SIZE", 0.0) for v in d.values()) * 1024 * 2
+    step_wr = sum(v.get("WRITE_SIZE", 0.0) for v in d.values()) * 1024
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_hash import kernel_hash
+    try:
+        commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                text=True).stdout.strip() or None
+    except Exception:
+        commit = None
     out = {
+        # which build the counters belong to: bench.py compares these hashes with the library it is running and flags
+        # the figure as stale when they differ (the GPU box has no .git: `commit` is then filled in by --collect)
+        "kernel_object_hash": kernel_hash("k_trace"), "library_kernels_hash": kernel_hash("k_"), "commit": commit,
+        "steps_profiled": 1,
+        "hbm_bytes_per_step_all_kernels": step_rd + step_wr,
+        "hbm_read_bytes_per_step_all_kernels": step_rd, "hbm_write_bytes_per_step_all_kernels": step_wr,
+        "per_kernel_hbm_bytes_per_step": {k: v.get("FETCH_SIZE", 0.0) * 2048 + v.get("WRITE_SIZE", 0.0) * 1024 for k, v in d.items()},
         "kernel": key, "workload": tag, "launches": n,
         "FETCH_SIZE_KB_sum": t["FETCH_SIZE"], "WRITE_SIZE_KB_sum": t["WRITE_SIZE"],
         "hbm_read_bytes_per_launch_raw": rd_raw,
@@ -45,7 +64,19 @@ def collect(tag, rnd):
     shutil.copy(ks[0], os.path.join(prof, f"{rnd}_kernel_stats_{tag}.csv"))
     shutil.copy(os.path.join(src, "pmc_summary.json"), os.path.join(prof, f"{rnd}_pmc_summary_{tag}.json"))
     shutil.copy(os.path.join(src, "bench_full.json"), os.path.join(prof, f"{rnd}_bench_{tag}.json"))
-    shutil.copy(os.path.join(src, f"trace_pmc_{tag}.json"), os.path.join(prof, f"trace_pmc_{tag}.json"))
+    tp = json.load(open(os.path.join(src, f"trace_pmc_{tag}.json")))
+    if not tp.get("commit"):  # staged on the GPU box (no .git there): the commit whose tree was profiled = HEAD here, if the
+        import subprocess     # library's kernels still hash to what was profiled
+        sys_path = os.path.join(ROOT, "tools")
+        import sys
+        sys.path.insert(0, sys_path)
+        from kernel_hash import kernel_hash
+        if kernel_hash("k_") == tp.get("library_kernels_hash"):
+            dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "rustraytracer_amd", "include"],
+                                   stdout=subprocess.PIPE, text=True).stdout.strip()
+            head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], stdout=subprocess.PIPE, text=True).stdout.strip()
+            tp["commit"] = head + ("+uncommitted" if dirty else "")
+    json.dump(tp, open(os.path.join(prof, f"trace_pmc_{tag}.json"), "w"), indent=1)
     b = json.load(open(os.path.join(src, "bench_full.json")))
     sb = json.load(open(os.path.join(src, "stats_bench.json")))
     for r in csv.DictReader(open(ks[0])):

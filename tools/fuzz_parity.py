@@ -4,9 +4,12 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes as C
+
 import numpy as np
 
 import rustraytracer_amd as rr
+from rustraytracer_amd import _ffi as F
 from tests import oracle_ffi as O
 from tests.test_gpu_arms import emitter_scene
 
@@ -38,19 +41,25 @@ for case in range(n_cases):
     seed = int(rng.integers(1 << 30))
     sc = make(faces, variant)
     gs = ctx.upload(sc, device_build=dev_build)
+    # round 3: a third of the cases through the lens arm of Camera::get_ray (geometry.rs:177-190): the preset's camera
+    # with lens_radius > 0 (the frame u, v and the focus plane stay the preset's)
+    cam = F.rt_camera()
+    C.memmove(C.byref(cam), sc.camera, C.sizeof(cam))
+    lens = float(rng.choice([0.0, 0.0, 0.08, 2.5]))
+    cam.lens_radius = lens
     acc = nacc = None
     tot = np.zeros(5, dtype=np.int64)
     for rank in range(world):
         cfg = rr.make_cfg(W, H, spp, max_depth=depth, seed=seed, paths_in_flight=pif, tile_rank=rank, tile_world=world)
-        r, n, s = ctx.render(gs, sc.camera, cfg)
+        r, n, s = ctx.render(gs, cam, cfg)
         acc = r if acc is None else acc + r
         nacc = n if nacc is None else nacc + n
         tot += np.array([s.rays, s.rays_extension, s.rays_shadow, s.rays_probe, s.vertices_shaded])
-    ro, no, so = O.OracleScene(sc).render(sc.camera, rr.make_cfg(W, H, spp, max_depth=depth, seed=seed), O.ORDERED, 16)
+    ro, no, so = O.OracleScene(sc).render(cam, rr.make_cfg(W, H, spp, max_depth=depth, seed=seed), O.ORDERED, 16)
     same = np.array_equal(acc, ro, equal_nan=True) and np.array_equal(nacc, no)
     cnt = tuple(tot) == (so.rays, so.rays_extension, so.rays_shadow, so.rays_probe, so.vertices_shaded)
     bad += not (same and cnt)
-    print(f"{case:3d} {name:20s} faces {faces:6d} v{variant} {W}x{H}@{spp} depth {depth} pool {pif} ranks {world} "
+    print(f"{case:3d} {name:20s} faces {faces:6d} v{variant} {W}x{H}@{spp} depth {depth} pool {pif} ranks {world} lens {lens} "
           f"{'lbvh' if dev_build else 'sah '} rays {int(tot[0]):9d} film {'==' if same else 'DIFF'} counters {'==' if cnt else 'DIFF'}",
           flush=True)
     gs.close()
