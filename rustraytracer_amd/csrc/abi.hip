@@ -708,6 +708,9 @@ static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cac
     for (const auto& m : s->meshes) any_normals = any_normals || !m.n.empty();
     if (np >= kMetaMatMask || s->mats.size() >= kMetaMatMask) return fail(RT_ERR_UNSUPPORTED, "too many primitives or materials");
     const auto t0 = std::chrono::steady_clock::now();
+#if RT_BVH8
+    flags &= ~(uint32_t)RT_COMMIT_DEVICE_LBVH;  // (experiment build) the 8-wide tree only comes from the host builder
+#endif
     if (flags & RT_COMMIT_DEVICE_LBVH) {
         // next-row f3: the tree is built where the primitives already are (bvh_gpu.hip)
         DeviceBvh gb;
@@ -728,9 +731,32 @@ static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cac
         t->info.build_device_ms = gb.build_ms;
     } else {
         if (!cache.valid) {
+#if RT_BVH8
+        // experiment RT_BVH8: the 8-wide tree with 8-bit boxes (scene_dev.h: DevNode8); `nodes` carries its 128-B records
+        struct {
+            std::vector<DevNode> nodes;
+            std::vector<uint32_t> order;
+            uint32_t depth = 0;
+        } bvh;
+        {
+            Bvh8Out b8;
+            build_bvh8(s->prims.data(), s->prims.size(), b8);
+            if (b8.stack_need + 2 > (uint32_t)(kLdsStack + kOvfStack))
+                return fail(RT_ERR_UNSUPPORTED, "BVH8 stack need %u exceeds the traversal stack", b8.stack_need);
+            static_assert(sizeof(DevNode) == sizeof(DevNode8), "node records share the array");
+            bvh.nodes.resize(b8.nodes.size());
+            std::memcpy(bvh.nodes.data(), b8.nodes.data(), b8.nodes.size() * sizeof(DevNode8));
+            bvh.order = std::move(b8.order);
+            bvh.depth = b8.depth;
+            if (getenv("RT_DIAG"))
+                fprintf(stderr, "[rt diag] bvh8: %zu nodes, depth %u, stack need %u, decoded/exact child area %.4f\n",
+                        bvh.nodes.size(), b8.depth, b8.stack_need, b8.quant_area_ratio);
+        }
+#else
         BvhOut bvh;
         t->info.build_from_cache = (uint32_t)build_bvh_shared(s->prims.data(), s->prims.size(), bvh);
         if (bvh.depth + 1 > (uint32_t)kMaxBvhDepth) return fail(RT_ERR_UNSUPPORTED, "BVH depth %u exceeds the traversal stack", bvh.depth);
+#endif
         // leaf-ordered triangle vertices + ids
         std::vector<uint32_t>& leaf_prim = cache.leaf_prim;
         std::vector<double>& leaf_tri = cache.leaf_tri;
@@ -765,7 +791,9 @@ static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cac
             }
         }
         cache.nodes = std::move(bvh.nodes);
+#if !RT_BVH8
         top_of_tree_first(cache.nodes, 256);
+#endif
         cache.depth = bvh.depth;
         cache.n_tri = n_tri_host;
         cache.valid = true;
@@ -803,7 +831,11 @@ static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cac
     t->info.n_others = np - n_tri;
     t->info.n_bvh_nodes = d.n_nodes;
     t->info.bvh_depth = depth;
+#if RT_BVH8
+    t->info.node_bytes = 80;  // bytes a node visit requests: five 16-B loads of the 128-B record
+#else
     t->info.node_bytes = sizeof(DevNode);
+#endif
     // bytes a primitive test requests from its leaf_trav line: the nine coordinates / v[5] + meta, + the index word
     t->info.tri_bytes = 9 * sizeof(double) + sizeof(uint32_t);
     t->info.other_bytes = 6 * sizeof(double) + sizeof(uint32_t);

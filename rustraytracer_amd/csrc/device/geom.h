@@ -479,32 +479,53 @@ struct TravCount {
 #ifndef RT_TRACE_WAVES
 #define RT_TRACE_WAVES 4
 #endif
+#ifndef RT_BVH8
+#define RT_BVH8 0  // (experiment, round 3) 1: the 8-wide tree with 8-bit child boxes (scene_dev.h: DevNode8) replaces the BVH4
+#endif
 constexpr int kLdsStack = RT_LDS_STACK;
+#if RT_BVH8
+constexpr int kOvfStack = 98;  // an 8-wide node pushes up to seven children; bvh_build.cpp bounds the need by 16 + 98
+#else
 constexpr int kOvfStack = 3 * kMaxBvhDepth + 2 - kLdsStack;  // a 4-wide node pushes up to three children
+#endif
 #ifndef RT_LDS_NODES
 #define RT_LDS_NODES 0
 #endif
+#ifndef RT_LEAF_PREFETCH
+#define RT_LEAF_PREFETCH 0  // (experiment) touch a leaf's record line when the traversal reaches the leaf, not when it is tested
+#endif
+// (Round 3) The struct holds two POINTERS and nothing else, so that it lives in registers: with the overflow array inside it
+// the whole struct sat in scratch, and every push / pop first re-read the LDS base and the stride from scratch
+// (scratch_load + s_waitcnt vmcnt(0) + a quarter-rate v_mul_lo_u32 per stack access), and the pop loop read its entries
+// through a generic pointer (flat_load + vmcnt(0) lgkmcnt(0)).  The stride is the block size of every traversing kernel.
+constexpr int kStackStride = 256;
 struct TravStack {
-    int2* lds;       // &lds_stack[0][threadIdx.x], stride = blockDim.x entries
-    int lds_stride;  // threads per block
-    int32_t ovf[kOvfStack];
+    int2* lds;       // &lds_stack[threadIdx.x]; entry i at lds[i * kStackStride]
+    int32_t* ovf;    // the kernel's private overflow array, kOvfStack entries
 #if RT_LDS_NODES > 0
     const DevNode* top_nodes = nullptr;  // LDS copy of nodes[0, n_top) (k_trace only)
     uint32_t n_top = 0;
 #endif
 };
+#define RT_TRAV_STACK(ts, lds_array)            \
+    int32_t ts##_ovf_store[kOvfStack];          \
+    TravStack ts;                               \
+    ts.lds = &(lds_array)[threadIdx.x];         \
+    ts.ovf = ts##_ovf_store;
 RTD void stack_push(TravStack& ts, int sp, int32_t node, float t) {
     if (sp < kLdsStack)
-        ts.lds[sp * ts.lds_stride] = make_int2(node, __float_as_int(t));
+        ts.lds[sp * kStackStride] = make_int2(node, __float_as_int(t));
     else
         ts.ovf[sp - kLdsStack] = node;
 }
 RTD void stack_get(const TravStack& ts, int sp, int32_t& node, float& t) {
-    if (sp < kLdsStack) {
-        const int2 v = ts.lds[sp * ts.lds_stride];
-        node = v.x;
-        t = __int_as_float(v.y);
-    } else {
+    // The LDS read is unconditional (index clamped), the rare overflow entry overrides it: two loads of different address
+    // spaces in the two arms of one `if` were merged into a flat load by the compiler.
+    const int2 v = ts.lds[(sp < kLdsStack ? sp : kLdsStack - 1) * kStackStride];
+    node = v.x;
+    t = __int_as_float(v.y);
+    asm volatile("" : "+v"(node));  // (opaque copy: keeps this a ds_read -- see above)
+    if (sp >= kLdsStack) {
         node = ts.ovf[sp - kLdsStack];
         t = 0.0f;
     }
@@ -526,7 +547,11 @@ struct Trav {
     uint32_t best_slot;  // leaf slot of best_prim (| kLeafOther)
     int sp;
     bool done;
+#if RT_LEAF_PREFETCH
+    uint32_t pf;  // the leaf_prim word of the leaf `cur` points at, fetched when the leaf was reached (leaf_touch)
+#endif
 };
+
 
 // Interior-node boxes only cull: a primitive is gated by the f64 slab test of its OWN box in leaf_step
 // (the reference's semantics, hittable.rs:625), and every ancestor box contains that box, so an ancestor
@@ -615,8 +640,27 @@ RTD void trav_pop(Trav& tv, TravStack& ts) {
     tv.done = true;
 }
 
+// (experiment RT_LEAF_PREFETCH) A lane that has just reached a leaf usually waits a round or more for the wave's next
+// primitive round (majority scheduling).  Fetching the leaf record's index word right away -- the one word of the
+// record that does not depend on the ray -- starts the line on its way to L1 during that wait, and leaf_step has one
+// load less to issue.  Loads return in order, so the older fetch never delays the round that follows.
+RTD void leaf_touch(Trav& tv, const DevScene& sc) {
+#if RT_LEAF_PREFETCH
+    if (!tv.done && tv.cur < 0) {
+        const uint32_t code = (uint32_t)(-1 - tv.cur);
+        const uint32_t slot = (code & ~kLeafCodeOther) >> 3;
+#ifdef RT_F32
+        tv.pf = sc.leaf_prim[slot];
+#else
+        tv.pf = reinterpret_cast<const uint32_t*>(sc.leaf_trav + (size_t)slot * 16)[30];
+#endif
+    }
+#endif
+}
+
 // One internal node: test its four children (one 128-B fetch), descend into the nearest hit and push
 // the others so that they pop nearest-first.
+#if !RT_BVH8
 template <bool COUNT>
 RTD void node_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
     // near / far plane rows of the node picked by the direction signs (rows: lo_x lo_y lo_z hi_x hi_y hi_z,
@@ -686,6 +730,118 @@ RTD void node_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
     if (nh > 1) { stack_push(ts, tv.sp, c1, d1); tv.sp++; }
     tv.cur = c0;
 }
+#endif  // !RT_BVH8
+
+#if RT_BVH8
+// ---- experiment RT_BVH8: one 8-wide node with 8-bit child boxes (scene_dev.h: DevNode8), five 16-B loads.
+// plane = origin + q * 2^e, so the ray parameter of a plane is
+//     t = (plane - o) / d = q * (2^e * inv) + (origin - o) * inv  ~  fma(q, s, b),   s = 2^e * inv32 (exact scaling),
+//     b = fma(origin, inv32, c),  c = the per-ray constant of node_step (-(o * inv32) -/+ its rounding slack).
+// Error against the f64 value, beyond what node_step's analysis covers (inv32 vs 1/d, the rounding of c, the single
+// rounding of the last fma -- all relative to |t| or folded into c): the rounding of b, 2^-24 |b|, where |b| -- the
+// parameter of the node's origin plane -- can be far larger than |t| for a ray that starts inside the node.  It is
+// folded into b as an absolute slack of 2^-21 |b| (lower for the near planes, higher for the far planes).  The 8-bit
+// planes themselves are conservative by construction (bvh_build.cpp: lower planes rounded down, upper planes up).
+// Children: slots [0, ni) nodes child_base + slot, [ni, nt) triangle leaves, [nt, nv) sphere / rect leaves at leaf slot
+// leaf_base + slot - ni.  Hit children are ordered by a 32-bit key = entry parameter (>= 0, so its bit pattern orders
+// like the value) with the low three mantissa bits replaced by the slot number: an 8-key sorting network of
+// v_min_u32 / v_max_u32 pairs, no payload to carry.  The entry parameter that goes on the stack is the key with
+// those bits cleared, i.e. rounded DOWN by at most 2^-20 relative: pop-time pruning only gets more conservative.
+template <bool COUNT>
+RTD void node_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
+    const char* nb = reinterpret_cast<const char*>(sc.nodes) + (size_t)(uint32_t)tv.cur * 128u;
+    const uint4 h0 = *reinterpret_cast<const uint4*>(nb);
+    const uint4 h1 = *reinterpret_cast<const uint4*>(nb + 16u);
+    const uint4 qa = *reinterpret_cast<const uint4*>(nb + 32u);  // lo_x[8] lo_y[8]
+    const uint4 qb = *reinterpret_cast<const uint4*>(nb + 48u);  // lo_z[8] hi_x[8]
+    const uint4 qc = *reinterpret_cast<const uint4*>(nb + 64u);  // hi_y[8] hi_z[8]
+    if (COUNT) tc->nodes++;
+    const float tmin32 = float_lower(tv.tmin);
+    const float tmax32 = (float)tv.tmax * (1.0f + kNodeSlack);
+    const float lim32 = __builtin_fminf((float)prune_limit(tv) * (1.0f + kNodeSlack), tmax32);
+    const float ox = __uint_as_float(h0.x), oy = __uint_as_float(h0.y), oz = __uint_as_float(h0.z);
+    // cell sizes as floats: the stored byte IS the exponent field
+    const float cx = __uint_as_float((h0.w & 0xffu) << 23), cy = __uint_as_float(((h0.w >> 8) & 0xffu) << 23),
+                cz = __uint_as_float(((h0.w >> 16) & 0xffu) << 23);
+    const float sx = cx * tv.ix, sy = cy * tv.iy, sz = cz * tv.iz;
+    float bnx = __builtin_fmaf(ox, tv.ix, tv.cnx), bny = __builtin_fmaf(oy, tv.iy, tv.cny), bnz = __builtin_fmaf(oz, tv.iz, tv.cnz);
+    float bfx = __builtin_fmaf(ox, tv.ix, tv.cfx), bfy = __builtin_fmaf(oy, tv.iy, tv.cfy), bfz = __builtin_fmaf(oz, tv.iz, tv.cfz);
+    bnx = __builtin_fmaf(-__builtin_fabsf(bnx), kNodeSlack, bnx);
+    bny = __builtin_fmaf(-__builtin_fabsf(bny), kNodeSlack, bny);
+    bnz = __builtin_fmaf(-__builtin_fabsf(bnz), kNodeSlack, bnz);
+    bfx = __builtin_fmaf(__builtin_fabsf(bfx), kNodeSlack, bfx);
+    bfy = __builtin_fmaf(__builtin_fabsf(bfy), kNodeSlack, bfy);
+    bfz = __builtin_fmaf(__builtin_fabsf(bfz), kNodeSlack, bfz);
+    // near / far rows by the direction signs (two dwords = eight slots each)
+    const bool ngx = (__float_as_uint(tv.ix) >> 31) != 0u, ngy = (__float_as_uint(tv.iy) >> 31) != 0u,
+               ngz = (__float_as_uint(tv.iz) >> 31) != 0u;
+    const uint32_t nx0 = ngx ? qb.z : qa.x, nx1 = ngx ? qb.w : qa.y, fx0 = ngx ? qa.x : qb.z, fx1 = ngx ? qa.y : qb.w;
+    const uint32_t ny0 = ngy ? qc.x : qa.z, ny1 = ngy ? qc.y : qa.w, fy0 = ngy ? qa.z : qc.x, fy1 = ngy ? qa.w : qc.y;
+    const uint32_t nz0 = ngz ? qc.z : qb.x, nz1 = ngz ? qc.w : qb.y, fz0 = ngz ? qb.x : qc.z, fz1 = ngz ? qb.y : qc.w;
+    const uint32_t ni = h1.z & 0xffu, nt = (h1.z >> 8) & 0xffu, nv = (h1.z >> 16) & 0xffu;
+#define RT_Q(w, k) ((float)(((w) >> (8 * (k))) & 0xffu))
+#define RT_NODE8_CHILD(c, NX, NY, NZ, FX, FY, FZ, k, key)                                                  \
+    uint32_t key;                                                                                          \
+    {                                                                                                      \
+        const float m_ = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(RT_Q(NX, k), sx, bnx),             \
+                                                         __builtin_fmaf(RT_Q(NY, k), sy, bny)),            \
+                                         __builtin_fmaf(RT_Q(NZ, k), sz, bnz));                            \
+        const float f_ = __builtin_fminf(__builtin_fminf(__builtin_fmaf(RT_Q(FX, k), sx, bfx),             \
+                                                         __builtin_fmaf(RT_Q(FY, k), sy, bfy)),            \
+                                         __builtin_fmaf(RT_Q(FZ, k), sz, bfz));                            \
+        const float e_ = __builtin_fmaxf(__builtin_fmaf(-__builtin_fabsf(m_), kNodeSlack, m_), tmin32);     \
+        const float x_ = __builtin_fminf(__builtin_fmaf(__builtin_fabsf(f_), kNodeSlack, f_), lim32);      \
+        key = (e_ <= x_ && (uint32_t)(c) < nv) ? ((__float_as_uint(e_) & 0x7ffffff8u) | (uint32_t)(c)) : 0xffffffffu; \
+    }
+    RT_NODE8_CHILD(0, nx0, ny0, nz0, fx0, fy0, fz0, 0, k0)
+    RT_NODE8_CHILD(1, nx0, ny0, nz0, fx0, fy0, fz0, 1, k1)
+    RT_NODE8_CHILD(2, nx0, ny0, nz0, fx0, fy0, fz0, 2, k2)
+    RT_NODE8_CHILD(3, nx0, ny0, nz0, fx0, fy0, fz0, 3, k3)
+    RT_NODE8_CHILD(4, nx1, ny1, nz1, fx1, fy1, fz1, 0, k4)
+    RT_NODE8_CHILD(5, nx1, ny1, nz1, fx1, fy1, fz1, 1, k5)
+    RT_NODE8_CHILD(6, nx1, ny1, nz1, fx1, fy1, fz1, 2, k6)
+    RT_NODE8_CHILD(7, nx1, ny1, nz1, fx1, fy1, fz1, 3, k7)
+#undef RT_NODE8_CHILD
+#undef RT_Q
+    // 19-comparator sorting network for 8 keys (misses = 0xffffffff sink to the end)
+#define RT_KSWAP(a, b)                                \
+    {                                                 \
+        const uint32_t lo_ = a < b ? a : b;           \
+        b = a < b ? b : a;                            \
+        a = lo_;                                      \
+    }
+    RT_KSWAP(k0, k1) RT_KSWAP(k2, k3) RT_KSWAP(k4, k5) RT_KSWAP(k6, k7)
+    RT_KSWAP(k0, k2) RT_KSWAP(k1, k3) RT_KSWAP(k4, k6) RT_KSWAP(k5, k7)
+    RT_KSWAP(k1, k2) RT_KSWAP(k5, k6) RT_KSWAP(k0, k4) RT_KSWAP(k3, k7)
+    RT_KSWAP(k1, k5) RT_KSWAP(k2, k6)
+    RT_KSWAP(k1, k4) RT_KSWAP(k3, k6)
+    RT_KSWAP(k2, k4) RT_KSWAP(k3, k5)
+    RT_KSWAP(k3, k4)
+#undef RT_KSWAP
+    if (k0 == 0xffffffffu) {
+        trav_pop(tv, ts);
+        return;
+    }
+    const uint32_t cbase = h1.x, lbase = h1.y - ni;  // leaf slot of child `slot` = lbase + slot
+    auto child_ref = [&](uint32_t key) -> int32_t {
+        const uint32_t slot = key & 7u;
+        const uint32_t leaf = ((lbase + slot) << 3) | (slot >= nt ? kLeafCodeOther : 0u);
+        return slot < ni ? (int32_t)(cbase + slot) : -1 - (int32_t)leaf;
+    };
+    // farthest first, so that the nearest pending child is on top of the stack; a wave-uniform test skips the pushes
+    // no lane needs (most nodes have two or three hit children)
+#define RT_PUSH8(key)                                                                  \
+    if (__ballot(key != 0xffffffffu) != 0ull) {                                        \
+        if (key != 0xffffffffu) {                                                      \
+            stack_push(ts, tv.sp, child_ref(key), __uint_as_float(key & 0x7ffffff8u)); \
+            tv.sp++;                                                                   \
+        }                                                                              \
+    }
+    RT_PUSH8(k7) RT_PUSH8(k6) RT_PUSH8(k5) RT_PUSH8(k4) RT_PUSH8(k3) RT_PUSH8(k2) RT_PUSH8(k1)
+#undef RT_PUSH8
+    tv.cur = child_ref(k0);
+}
+#endif  // RT_BVH8
 
 // One primitive of the current leaf (leaf code: -1 - ((first*8 + count-1) | kLeafCodeOther?)); pops after
 // the last one.  Ties in t go to the larger prim index (ABI tie rule).
@@ -702,12 +858,20 @@ RTD void leaf_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
     const uint32_t first = (code & ~kLeafCodeOther) >> 3, count = (code & 7u) + 1u;
     const uint32_t slot = first;
 #ifdef RT_F32
+#if RT_LEAF_PREFETCH
+    const uint32_t e = tv.pf;
+#else
     const uint32_t e = sc.leaf_prim[slot];
+#endif
     const float* tvp = sc.leaf_tri32 + (size_t)slot * 9;  // RT_KEEP_F64
 #else
     // one aligned 128-B line per slot (scene_dev.h: leaf_trav): geometry and the primitive index word
     const f64_t* rec = sc.leaf_trav + (size_t)slot * 16;
+#if RT_LEAF_PREFETCH
+    const uint32_t e = tv.pf;
+#else
     const uint32_t e = reinterpret_cast<const uint32_t*>(rec)[30];
+#endif
 #endif
     double t = 0.0;
     int32_t pi = -1;
@@ -847,6 +1011,7 @@ RTD int32_t closest_hit(const DevScene& sc, D3 o, D3 dir, double tmin, double tm
             node_step<COUNT>(tv, sc, ts, tc);
         else
             leaf_step<COUNT>(tv, sc, ts, tc);
+        leaf_touch(tv, sc);
     }
     t_out = tv.best_t;
     if (slot_out) *slot_out = tv.best_slot;

@@ -234,9 +234,7 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
     const uint32_t lane = threadIdx.x & 63u;
     TravCount tc{0, 0, 0};
     __shared__ int2 lds_stack[kLdsStack * 256];
-    TravStack ts;
-    ts.lds = &lds_stack[threadIdx.x];
-    ts.lds_stride = 256;
+    RT_TRAV_STACK(ts, lds_stack)
 #if RT_LDS_NODES > 0
     // (experiment, BASELINE north_star: "BVH-node tiles staged in LDS") the first RT_LDS_NODES nodes -- the top of the
     // tree, which rt_scene_commit lays out breadth-first -- are copied into LDS once per block; node_step fetches
@@ -384,13 +382,19 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
                 diag_rounds[0]++;
                 diag_rounds[1] += (uint32_t)cn;
             }
-            if (at_node) node_step<COUNT>(tv, sc, ts, &tc);
+            if (at_node) {
+                node_step<COUNT>(tv, sc, ts, &tc);
+                leaf_touch(tv, sc);
+            }
         } else if (cl > 0) {
             if (COUNT) {  // diagnostic: lanes busy per primitive round
                 diag_rounds[2]++;
                 diag_rounds[3] += (uint32_t)cl;
             }
-            if (at_leaf) leaf_step<COUNT, SIMPLE>(tv, sc, ts, &tc);
+            if (at_leaf) {
+                leaf_step<COUNT, SIMPLE>(tv, sc, ts, &tc);
+                leaf_touch(tv, sc);
+            }
         }
         if (has_ray && tv.done) {
             if (COUNT) {  // diagnostic: longest traversal, and how many rays needed more than 64 / 256 steps
@@ -434,9 +438,7 @@ __global__ __launch_bounds__(256) void k_intersect_batch(DevScene sc, const rt_r
     if (i >= n) return;
     const rt_ray r = rays[i];
     TravCount tc{0, 0, 0};
-    TravStack ts;
-    ts.lds = &lds_stack[threadIdx.x];
-    ts.lds_stride = 256;
+    RT_TRAV_STACK(ts, lds_stack)
     double t;
     const int32_t prim = closest_hit<true>(sc, d3(r.origin[0], r.origin[1], r.origin[2]),
                                            d3(r.dir[0], r.dir[1], r.dir[2]), r.tmin, r.tmax, t, ts, &tc);
@@ -1034,9 +1036,7 @@ __global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathS
     uint32_t slot = 0;
     bool alive = false;
     bool list_done = false;  // wave-uniform
-    TravStack ts;
-    ts.lds = &lds_stack[threadIdx.x];
-    ts.lds_stride = 256;
+    RT_TRAV_STACK(ts, lds_stack)
     TravCount tc{0, 0, 0};
     unsigned long long n_r1 = 0, n_r2 = 0, n_r3 = 0, n_v = 0;
     uint32_t n_traced = 0;  // wave-uniform: rays this wave traced
