@@ -527,7 +527,8 @@ RTD void stack_get(const TravStack& ts, int sp, int32_t& node, float& t) {
     asm volatile("" : "+v"(node));  // (opaque copy: keeps this a ds_read -- see above)
     if (sp >= kLdsStack) {
         node = ts.ovf[sp - kLdsStack];
-        t = 0.0f;
+        asm volatile("" : "+v"(node));  // the scratch load is awaited HERE, in the rare branch, not by an s_waitcnt vmcnt(0)
+        t = 0.0f;                       // at the merge point that every pop would pay (stores may be in flight)
     }
 }
 

@@ -871,6 +871,8 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc
                 s_alive[wave] = 0u;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");  // the LDS writes have landed before the wave ends
+            RT_PROF(8)
+            RT_PROF_FLUSH
             return;
         }
         if (lane == 0) {
@@ -929,7 +931,11 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc
             if (lane == 0) prev = __hip_atomic_fetch_add(&s_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             prev = (uint32_t)__builtin_amdgcn_readfirstlane((int)prev);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-            if (prev + 1u < n_part) return;
+            RT_PROF(9)
+            if (prev + 1u < n_part) {
+                RT_PROF_FLUSH
+                return;
+            }
             // last wave: totals, one reservation, all entries kind by kind ([ext of the waves][shadow ...][probe ...])
             uint32_t cnt[3][4], tk[3] = {0, 0, 0}, tv = 0;
             for (uint32_t w = 0; w < 4; w++) {
@@ -957,6 +963,8 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc
                     if (lane < cnt[k][w]) queue_out[o + lane] = s_stage[w][k][lane];
                     o += cnt[k][w];
                 }
+            RT_PROF(9)
+            RT_PROF_FLUSH
             return;
         }
         __syncthreads();

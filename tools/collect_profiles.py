@@ -23,8 +23,20 @@ def stage(tag):
     rd_raw = t["FETCH_SIZE"] * 1024 / n
     wr = t["WRITE_SIZE"] * 1024 / n
     # every kernel of the profiled step: HBM bytes of the whole step (bench.py: roofline.hbm_frac_rocprof_step)
-    step_rd = sum(v.get("FETCH_SIZE", 0.0) for v in d.values()) * 1024 * 2
-    step_wr = sum(v.get("WRITE_SIZE", 0.0) for v in d.values()) * 1024
+    # The profiled command (tools/prof_pmc.sh: bench.py --steps 1 --warmup 0) renders the frame TWICE: the timed step and
+    # the instrumented counting pass bench.py always adds.  Kernels with a COUNT template flag exist once per pass
+    # (k_trace<false, ..> / k_tail<.., false> = the timed step, <true, ..> / <.., true> = the counting pass, left out);
+    # every other kernel ran in both passes under one name, so its sums are halved (the two passes do identical work).
+    def passes(name):
+        if name.startswith(("rtd::k_trace<true", "rtd32::k_trace<true")) or (name.startswith(("rtd::k_tail", "rtd32::k_tail")) and name.rstrip(">").endswith("true")):
+            return 0
+        if name.startswith(("rtd::k_trace<false", "rtd32::k_trace<false")) or name.startswith(("rtd::k_tail", "rtd32::k_tail")):
+            return 1
+        return 2
+    per_kernel = {k: (v.get("FETCH_SIZE", 0.0) * 2048 / passes(k), v.get("WRITE_SIZE", 0.0) * 1024 / passes(k))
+                  for k, v in d.items() if passes(k)}
+    step_rd = sum(r for r, _ in per_kernel.values())
+    step_wr = sum(w for _, w in per_kernel.values())
     import subprocess
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -41,7 +53,7 @@ def stage(tag):
         "steps_profiled": 1,
         "hbm_bytes_per_step_all_kernels": step_rd + step_wr,
         "hbm_read_bytes_per_step_all_kernels": step_rd, "hbm_write_bytes_per_step_all_kernels": step_wr,
-        "per_kernel_hbm_bytes_per_step": {k: v.get("FETCH_SIZE", 0.0) * 2048 + v.get("WRITE_SIZE", 0.0) * 1024 for k, v in d.items()},
+        "per_kernel_hbm_bytes_per_step": {k: r + w for k, (r, w) in per_kernel.items()},
         "kernel": key, "workload": tag, "launches": n,
         "FETCH_SIZE_KB_sum": t["FETCH_SIZE"], "WRITE_SIZE_KB_sum": t["WRITE_SIZE"],
         "hbm_read_bytes_per_launch_raw": rd_raw,
