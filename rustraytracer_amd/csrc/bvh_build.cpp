@@ -563,7 +563,7 @@ void build_bvh8(const rt_primitive* prims, size_t n, Bvh8Out& out) {
         out.stack_need = col.emit(root, 0, 0);
         out.depth = col.max_depth;
         out.quant_area_ratio = col.area_x > 0.0 ? col.area_q / col.area_x : 1.0;
-        if (out.stack_need + 2 <= 16u + 98u) return;  // geom.h: kLdsStack + the private overflow of the RT_BVH8 build
+        if (out.stack_need + 2 <= 12u + 98u) return;  // geom.h: kLdsStack + the private overflow of the RT_BVH8 build
     }
 }
 

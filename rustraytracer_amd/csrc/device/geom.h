@@ -473,11 +473,13 @@ struct TravCount {
 // a small private array that only keeps the node (popped unconditionally; its children are then
 // culled by their own slab tests).  Keeping the private part under ~256 B per lane matters: a larger
 // scratch frame makes every dispatch of the kernel pay a use-once scratch allocation (~0.1 ms).
+// Round 3: five waves per SIMD for k_trace (96 VGPRs, a handful spilled) with a 12-entry LDS stack (24 KB per block, five
+// blocks per CU): C4 k_trace 577 -> 561 ms, C3 105 -> 100.  With 16 entries five blocks do not fit the CU's LDS.
 #ifndef RT_LDS_STACK
-#define RT_LDS_STACK 16
+#define RT_LDS_STACK 12
 #endif
 #ifndef RT_TRACE_WAVES
-#define RT_TRACE_WAVES 4
+#define RT_TRACE_WAVES 5
 #endif
 #ifndef RT_BVH8
 #define RT_BVH8 0  // (experiment, round 3) 1: the 8-wide tree with 8-bit child boxes (scene_dev.h: DevNode8) replaces the BVH4
@@ -696,6 +698,7 @@ RTD void node_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
                                                          __builtin_fmaf(fy.c, tv.iy, tv.cfy)),         \
                                          __builtin_fmaf(fz.c, tv.iz, tv.cfz));                         \
         e = __builtin_fmaxf(__builtin_fmaf(-__builtin_fabsf(m_), kNodeSlack, m_), tmin32);             \
+        /* (the min with tmax32 also turns an all-NaN far side -- a ray along an axis -- into "unbounded") */ \
         const float x_ = __builtin_fminf(__builtin_fmaf(__builtin_fabsf(f_), kNodeSlack, f_), tmax32); \
         h = e <= x_ && e <= lim32 && cid != kNoChild;                                                  \
     }
