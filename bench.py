@@ -49,9 +49,14 @@ WORKLOADS = {
     "c5": ("plastic_dragon", dict(mesh_faces=871414, variant=2), 2048, 2048, 4096,
            "C5 dragon (procedural P-871k) smooth glass, 2048x2048 @ 4096 spp, max_depth 25"),
     "hdr": ("material_hdr", dict(variant=3, mesh_faces=150000), 512, 512, 64,
-            "row f4: material_hdr(3) rough glass under the procedural environment map, 3 x P-150k, 512x512 @ 64 spp"),
+            "row f4: material_hdr(3) rough glass; the reference's Mesh000/001.obj + envmap.hdr (--assets), P-150k for the "
+            "missing Mesh002.obj, 512x512 @ 64 spp"),
     "hdr1": ("material_hdr", dict(variant=1, mesh_faces=150000), 512, 512, 64,
-             "row f4: material_hdr(1) rose-gold metal under the procedural environment map, 3 x P-150k, 512x512 @ 64 spp"),
+             "row f4: material_hdr(1) rose-gold metal; the reference's Mesh000/001.obj + envmap.hdr (--assets), P-150k for "
+             "the missing Mesh002.obj, 512x512 @ 64 spp"),
+    "teapot": ("teapot_hdr", dict(mesh_faces=200000), 1280, 720, 64,
+               "row f4: teapot_hdr() (scenes.rs:744-808) smooth plastic, procedural lid + body (the reference's teapot meshes are "
+               "not in its checkout) under the reference's envmap.hdr, 1280x720 @ 64 spp"),
     "c1": ("cornell_box", dict(), 256, 256, 16, "C1 cornell_box 256x256 @ 16 spp"),
     "tiny": ("cornell_box_statue", dict(mesh_faces=20000, variant=0), 128, 128, 8, "tiny smoke workload"),
 }
@@ -110,6 +115,39 @@ def cpu_baseline(scene, W, H, target_s=9.0):
     return out
 
 
+_ASSET_DIR = None
+
+
+def asset_dir(spec):
+    """Where the row-f4 presets (material_hdr, teapot_hdr) find the reference's data files.  "golden" (default): the
+    committed fixtures tests/golden/assets/material (Mesh000/001.obj gzip-compressed, envmap.hdr), unpacked once into
+    a temporary directory -- they travel to the GPU box with the repo; "none": procedural stand-ins for everything; any
+    other value: a directory laid out like the reference's data/material (the build container has
+    /root/reference/data/material)."""
+    global _ASSET_DIR
+    if spec == "none":
+        return None
+    if spec != "golden":
+        return spec
+    if _ASSET_DIR is None:
+        import gzip
+        import shutil
+        import tempfile
+        src = os.path.join(ROOT, "tests", "golden", "assets", "material")
+        out = tempfile.mkdtemp(prefix="rr_assets_")
+        os.makedirs(os.path.join(out, "models"))
+        os.makedirs(os.path.join(out, "textures"))
+        for name in ("Mesh000.obj", "Mesh001.obj"):
+            with gzip.open(os.path.join(src, "models", name + ".gz"), "rb") as fi, open(os.path.join(out, "models", name), "wb") as fo:
+                shutil.copyfileobj(fi, fo)
+        shutil.copy(os.path.join(src, "textures", "envmap.hdr"), os.path.join(out, "textures", "envmap.hdr"))
+        _ASSET_DIR = out
+    return _ASSET_DIR
+
+
+ASSETS = "golden"
+
+
 class Bench:
     """One workload on this rank's GPU: scene resident, film on the device."""
 
@@ -121,6 +159,8 @@ class Bench:
         self.torch, self.rr = torch, rr
         self.name, self.rank, self.world, self.coll_dev = name, rank, world, coll_dev
         preset, kw, self.W, self.H, self.spp, self.desc = WORKLOADS[name]
+        if preset in ("material_hdr", "teapot_hdr"):
+            kw = dict(kw, mesh_path=asset_dir(ASSETS))
         self.scene = rr.Scene(preset, self.W / self.H, **kw)
         self.ctx = rr.Context(local_rank)
         self.gs = self.ctx.upload(self.scene)
@@ -275,7 +315,12 @@ def main():
                     help="f32 = the fast mode (RT_PRECISION_F32): reported, not the headline -- the metric is defined on the f64 parity mode")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: dry run of the N>1 control flow with several ranks sharing one GPU (films gathered on the host)")
+    ap.add_argument("--assets", default="golden",
+                    help='row-f4 workloads (hdr, hdr1, teapot): "golden" = the committed reference data files under tests/golden/assets, '
+                         '"none" = procedural stand-ins, or a directory laid out like the reference\'s data/material')
     args = ap.parse_args()
+    global ASSETS
+    ASSETS = args.assets
 
     import torch
     import torch.distributed as dist

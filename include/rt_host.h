@@ -20,7 +20,9 @@ typedef struct rrh_scene rrh_scene;
  * "cornell_box_statue" (scenes.rs:200-307), "plastic_dragon" (scenes.rs:310-375),
  * "sphere_roughness" (scenes.rs:474-546), "two_dragons" (scenes.rs:549-624),
  * "material_hdr" (scenes.rs:627-741; variant = mat_num, mesh_path = the
- * reference's data/material directory).
+ * reference's data/material directory), "teapot_hdr" (scenes.rs:744-808;
+ * mesh_path = a directory with models/Mesh00{0,1}.obj + textures/envmap.hdr,
+ * procedural stand-ins for what is missing).
  * mesh_faces: procedural stand-in face count (0 = preset default);
  * mesh_path: OBJ to load instead (NULL = procedural); variant: see scenes.cpp.   */
 int rrh_scene_build(const char* preset, double aspect_ratio, uint64_t mesh_faces, const char* mesh_path,

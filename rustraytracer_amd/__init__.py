@@ -7,5 +7,5 @@ library; the first call does, and raises if librt_amd.so has not been built.
 from . import _ffi  # noqa: F401
 from .api import (  # noqa: F401
     MAX_DEPTH, TILE_SIZE, Context, GpuScene, RtError, Scene, cornell_box, cornell_box_spheres,
-    cornell_box_statue, make_cfg, material_hdr, plastic_dragon, sphere_roughness, two_dragons, write_png,
+    cornell_box_statue, make_cfg, material_hdr, plastic_dragon, sphere_roughness, teapot_hdr, two_dragons, write_png,
 )

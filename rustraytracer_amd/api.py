@@ -211,6 +211,13 @@ def material_hdr(mat_num=0, aspect_ratio=1.0, mesh_faces=0, data_dir=None):
     return Scene("material_hdr", aspect_ratio, mesh_faces, data_dir, mat_num)
 
 
+def teapot_hdr(aspect_ratio=1.0, mesh_faces=0, data_dir=None):
+    """scenes.rs:744-808 (row f4): smooth-plastic teapot (two meshes) on a checkered floor under the environment map.
+    data_dir = a directory with models/Mesh000.obj, models/Mesh001.obj, textures/envmap.hdr (the reference's data/teapot
+    holds only the environment map); missing files -> procedural stand-ins."""
+    return Scene("teapot_hdr", aspect_ratio, mesh_faces, data_dir, 0)
+
+
 def write_png(path, rgb8):
     """rgb8: (H, W, 3) uint8 (Context.resolve_rgb8) -> PNG file, the last step of util::draw_picture (row f1)."""
     rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)

@@ -19,6 +19,7 @@ struct DeviceBvh {
     uint32_t depth = 0;            // depth of the 4-wide tree (root = 0)
     uint64_t n_triangles = 0;
     float build_ms = 0.0f;         // device time of the whole build (HIP events)
+    uint32_t rotation_passes = 0;  // refit passes that applied tree rotations (0: plain Morton-order tree)
 };
 
 // Builds the traversal structure of `n` primitives that are already resident in HBM (`d_prims`, with the

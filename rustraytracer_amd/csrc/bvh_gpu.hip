@@ -338,8 +338,32 @@ __device__ inline void child_box(const Tree& t, const rt_primitive* __restrict__
     }
 }
 
+// Tree rotations (Kensler 2008), fused into the refit: the thread that completes node p owns the whole subtree below
+// it, so it may exchange one child of p with a grandchild on the other side when that shrinks the box -- and with it
+// the surface-area cost -- of the child node that receives it:
+//     p = (L, R = (a, b))  ->  p = (a, R' = (L, b))   if area(L u b) < area(R),   and the three mirror cases.
+// A Morton-order tree splits space at fixed bit planes, so a large primitive or a cluster that straddles a plane
+// inflates a whole subtree; one rotation per node on the way up undoes the worst of it (node fetches per ray of the
+// device-built tree against the host SAH tree: DESIGN.md section 7).  Only with one primitive per leaf: a rotation breaks
+// the contiguity of a subtree's range of sorted positions, which multi-primitive leaf codes rely on.
+__device__ inline double box_area(const double* b) {
+    const double dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+__device__ inline void set_parent(const Tree& t, int32_t c, int32_t par) {
+    if (c >= 0)
+        t.parent[c] = par;
+    else
+        t.leaf_par[~c] = par;
+}
+__device__ inline double union_area(const double* a, const double* b) {
+    const double dx = fmax(a[3], b[3]) - fmin(a[0], b[0]), dy = fmax(a[4], b[4]) - fmin(a[1], b[1]),
+                 dz = fmax(a[5], b[5]) - fmin(a[2], b[2]);
+    return dx * dy + dy * dz + dz * dx;
+}
+
 __global__ __launch_bounds__(256) void kb_refit(const rt_primitive* __restrict__ prims,
-                                                const uint32_t* __restrict__ order, int n, Tree t) {
+                                                const uint32_t* __restrict__ order, int n, Tree t, int rotate) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     int p = t.leaf_par[j];
@@ -351,6 +375,58 @@ __global__ __launch_bounds__(256) void kb_refit(const rt_primitive* __restrict__
         bool tl, tr;
         child_box(t, prims, order, t.left[p], bl, tl);
         child_box(t, prims, order, t.right[p], br, tr);
+        if (rotate && kLeafTargetPrims == 1) {
+            const int32_t L = t.left[p], R = t.right[p];
+            // candidates: (side whose node is rebuilt, which of its children stays)
+            double best_gain = 0.0;
+            int best = -1;
+            double gb[4][6];  // boxes of the grandchildren: R.left, R.right, L.left, L.right
+            bool gt[4] = {false, false, false, false};
+            if (R >= 0) {
+                child_box(t, prims, order, t.left[R], gb[0], gt[0]);
+                child_box(t, prims, order, t.right[R], gb[1], gt[1]);
+                const double ar = box_area(br);
+                const double g0 = ar - union_area(bl, gb[1]);  // L <-> R.left : R' = (L, R.right)
+                const double g1 = ar - union_area(bl, gb[0]);  // L <-> R.right: R' = (R.left, L)
+                if (g0 > best_gain) { best_gain = g0; best = 0; }
+                if (g1 > best_gain) { best_gain = g1; best = 1; }
+            }
+            if (L >= 0) {
+                child_box(t, prims, order, t.left[L], gb[2], gt[2]);
+                child_box(t, prims, order, t.right[L], gb[3], gt[3]);
+                const double al = box_area(bl);
+                const double g2 = al - union_area(br, gb[3]);  // R <-> L.left : L' = (R, L.right)
+                const double g3 = al - union_area(br, gb[2]);  // R <-> L.right: L' = (L.left, R)
+                if (g2 > best_gain) { best_gain = g2; best = 2; }
+                if (g3 > best_gain) { best_gain = g3; best = 3; }
+            }
+            if (best >= 0) {
+                const bool right_side = best < 2;          // the node that is rebuilt
+                const int32_t N = right_side ? R : L;      // rebuilt node
+                const int32_t S = right_side ? L : R;      // p's other child, moves down into N
+                const bool take_left = (best & 1) == 0;    // N's left child moves up to p
+                const int32_t up = take_left ? t.left[N] : t.right[N];
+                const double* stay = gb[(right_side ? 0 : 2) + (take_left ? 1 : 0)];
+                const bool stay_tri = gt[(right_side ? 0 : 2) + (take_left ? 1 : 0)];
+                const double* sb = right_side ? bl : br;
+                const bool s_tri = right_side ? tl : tr;
+                if (take_left) t.left[N] = S; else t.right[N] = S;
+                set_parent(t, S, N);
+                if (right_side) t.left[p] = up; else t.right[p] = up;
+                set_parent(t, up, p);
+                double nb[6];
+                for (int a = 0; a < 3; a++) {
+                    nb[a] = fmin(sb[a], stay[a]);
+                    nb[3 + a] = fmax(sb[3 + a], stay[3 + a]);
+                }
+                for (int a = 0; a < 6; a++) t.box[(size_t)N * 6 + a] = nb[a];
+                t.all_tri[N] = (s_tri && stay_tri) ? 1u : 0u;
+                __threadfence();
+                // p's two children are now `up` and N: re-read their boxes for the union below
+                child_box(t, prims, order, t.left[p], bl, tl);
+                child_box(t, prims, order, t.right[p], br, tr);
+            }
+        }
         for (int a = 0; a < 3; a++) {
             t.box[(size_t)p * 6 + a] = fmin(bl[a], br[a]);
             t.box[(size_t)p * 6 + 3 + a] = fmax(bl[3 + a], br[3 + a]);
@@ -363,10 +439,6 @@ __global__ __launch_bounds__(256) void kb_refit(const rt_primitive* __restrict__
 // ---- 4-wide emission, one level per launch.  Work item = (binary node) | (4-wide node index << 32).
 __device__ inline bool leafable(const Tree& t, int32_t c) {
     return t.all_tri[c] != 0u && t.last[c] - t.first[c] + 1u <= (uint32_t)kLeafTargetPrims;
-}
-__device__ inline double box_area(const double* b) {
-    const double dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
-    return dx * dy + dy * dz + dz * dx;
 }
 
 __global__ __launch_bounds__(256) void kb_emit(const rt_primitive* __restrict__ prims,
@@ -450,6 +522,12 @@ __global__ __launch_bounds__(256) void kb_emit(const rt_primitive* __restrict__ 
 }
 
 __global__ void kb_next_level(BuildGlobals* g, int cur) { g->q_count[cur] = 0; }
+__global__ void kb_reset_emit(BuildGlobals* g) {  // a second emission (the rotation-free retry) starts over
+    g->node_count = 1;
+    g->q_count[0] = 1;
+    g->q_count[1] = 0;
+    g->overflow = 0;
+}
 
 // the scene is a single primitive: node 0 wraps its leaf
 __global__ void kb_single(const rt_primitive* __restrict__ prims, DevNode* nodes) {
@@ -610,26 +688,46 @@ int build_bvh_device(hipStream_t stream, const rt_primitive* d_prims, const DevM
         B_TRY(tmp.get(&t.all_tri, ni));
         B_TRY(tmp.get(&queue[0], ni));
         B_TRY(tmp.get(&queue[1], ni));
-        B_TRY(hipMemsetAsync(t.flag, 0, ni * sizeof(uint32_t), stream));
-        B_TRY(hipMemsetAsync(queue[0], 0, sizeof(ull), stream));  // first item: binary root 0 -> node 0
-        hipLaunchKernelGGL(kb_tree, dim3(nb), dim3(256), 0, stream, skeys, (int)n, t);
-        hipLaunchKernelGGL(kb_refit, dim3(nb), dim3(256), 0, stream, d_prims, order, (int)n, t);
-        int q = 0;
-        uint32_t count = 1;
-        levels = 0;
-        while (count > 0) {
-            if (levels >= (uint32_t)kMaxBvhDepth)
+        // Tree, refit with fused rotations (RT_LBVH_ROTATE_PASSES passes, default 2; 0 = the plain Morton-order tree), 4-wide
+        // emission.  Rotations can deepen the tree: if the result does not fit the traversal stack, the tree is rebuilt
+        // without them before giving up.
+        const int rot_default = getenv("RT_LBVH_ROTATE_PASSES") ? atoi(getenv("RT_LBVH_ROTATE_PASSES")) : 2;
+        for (int rot_passes = rot_default;; rot_passes = 0) {
+            B_TRY(hipMemsetAsync(t.flag, 0, ni * sizeof(uint32_t), stream));
+            B_TRY(hipMemsetAsync(queue[0], 0, sizeof(ull), stream));  // first item: binary root 0 -> node 0
+            hipLaunchKernelGGL(kb_reset_emit, dim3(1), dim3(1), 0, stream, g);
+            hipLaunchKernelGGL(kb_tree, dim3(nb), dim3(256), 0, stream, skeys, (int)n, t);
+            hipLaunchKernelGGL(kb_refit, dim3(nb), dim3(256), 0, stream, d_prims, order, (int)n, t, rot_passes > 0 ? 1 : 0);
+            for (int pass = 1; pass < rot_passes; pass++) {
+                B_TRY(hipMemsetAsync(t.flag, 0, ni * sizeof(uint32_t), stream));
+                hipLaunchKernelGGL(kb_refit, dim3(nb), dim3(256), 0, stream, d_prims, order, (int)n, t, 1);
+            }
+            int q = 0;
+            uint32_t count = 1;
+            levels = 0;
+            bool too_deep = false;
+            while (count > 0) {
+                if (levels >= (uint32_t)kMaxBvhDepth) {
+                    too_deep = true;
+                    break;
+                }
+                hipLaunchKernelGGL(kb_emit, dim3((count + 255u) / 256u), dim3(256), 0, stream, d_prims, order, t, queue[q],
+                                   queue[q ^ 1], g, q, pool, max_nodes);
+                hipLaunchKernelGGL(kb_next_level, dim3(1), dim3(1), 0, stream, g, q);
+                B_TRY(hipMemcpyAsync(&hg, g, sizeof(hg), hipMemcpyDeviceToHost, stream));
+                B_TRY(hipStreamSynchronize(stream));
+                count = hg.q_count[q ^ 1];
+                q ^= 1;
+                levels++;
+            }
+            if (!too_deep) {
+                r.rotation_passes = (uint32_t)rot_passes;
+                break;
+            }
+            if (rot_passes == 0)
                 return bfail(err, err_len, RT_ERR_UNSUPPORTED,
                              "device-built BVH is deeper than the traversal stack allows (%d levels): commit with the host builder",
                              kMaxBvhDepth);
-            hipLaunchKernelGGL(kb_emit, dim3((count + 255u) / 256u), dim3(256), 0, stream, d_prims, order, t, queue[q],
-                               queue[q ^ 1], g, q, pool, max_nodes);
-            hipLaunchKernelGGL(kb_next_level, dim3(1), dim3(1), 0, stream, g, q);
-            B_TRY(hipMemcpyAsync(&hg, g, sizeof(hg), hipMemcpyDeviceToHost, stream));
-            B_TRY(hipStreamSynchronize(stream));
-            count = hg.q_count[q ^ 1];
-            q ^= 1;
-            levels++;
         }
     }
     B_TRY(hipGetLastError());

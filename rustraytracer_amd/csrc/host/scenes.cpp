@@ -346,8 +346,70 @@ static bool material_hdr(const PresetParams& p, FlatScene& out, std::string& err
     return true;
 }
 
+// scenes.rs:744-808 teapot_hdr(), next-row f4: a smooth-plastic teapot (lid + body, two meshes of one material) on a
+// checkered floor rect under the environment map, camera from the Tungsten scene.  The reference reads
+// data/teapot/models/Mesh000.obj (lid) / Mesh001.obj (body) and data/material/textures/envmap.hdr; the checkout holds
+// the environment map (data/teapot/textures/envmap.hdr is the same file) but not the two teapot meshes, so -- like
+// dragon.obj and statue.obj -- they are replaced by procedural P-N meshes of a teapot's proportions unless `mesh_path`
+// names a directory that has models/Mesh000.obj and models/Mesh001.obj (and textures/envmap.hdr).
+static bool teapot_hdr(const PresetParams& p, FlatScene& out, std::string& err) {
+    (void)err;
+    Objects o;
+    Vec3 from = V(23.895, 11.2207, 0.0400773);
+    Vec3 dir = V(-0.939631, -0.342149, -0.00519335);
+    Vec3 to = V(from.x + dir.x, from.y + dir.y, from.z + dir.z);
+    Vec3 up = V(-0.342144, 0.939646, -0.00189103);
+    Camera camera = Camera::create(from, to, up, p.aspect_ratio, 35. / 2., 0.0, 10.);
+    const std::string root = (p.mesh_path && p.mesh_path[0]) ? std::string(p.mesh_path) : std::string();
+    {
+        rt_texture env;
+        std::string e2;
+        if (root.empty() || !Texture::new_hdr(o, root + "/textures/envmap.hdr", env, e2))
+            env = Texture::new_hdr_procedural(o, 512, 256);
+        o.textures.push_back(env);
+    }
+    o.lights.push_back(Light::make_infinite_light(o, nullptr, 1, 0));
+    const double floor_m[16] = {-39.9766, 39.9766, -1.74743e-006, 0, 4.94249e-006, 2.47125e-006, -56.5355, 0,
+                                -39.9766, -39.9766, -5.2423e-006, 0, 0, 0, 0, 1};
+    const Mat4 identity_transform = Mat4::identity();
+    const Mat4 floor_transform = Mat4::from_rows(floor_m);
+    const uint64_t faces = p.mesh_faces ? p.mesh_faces : 60000;
+    auto load = [&](const char* file, const Mat4& stand_in, uint64_t n_faces, Mesh& m) {
+        std::string e2;
+        if (!root.empty() && parse_obj(root + "/models/" + file, identity_transform, m, e2)) return;
+        m = procedural_mesh(n_faces, stand_in);
+    };
+    // stand-ins: the body ~ 12 x 6.3 x 8.1 resting on the floor (y = 0), the lid a flatter blob on top of it
+    Mesh lid, body;
+    const double lid_m[16] = {5., 0, 0, 0., 0, 3., 0, 6.9, 0, 0, 11., 0., 0, 0, 0, 1};
+    const double body_m[16] = {12., 0, 0, 0., 0, 9., 0, 3.15, 0, 0, 18., 0., 0, 0, 0, 1};
+    load("Mesh000.obj", Mat4::from_rows(lid_m), std::max<uint64_t>(faces / 8, 64), lid);
+    load("Mesh001.obj", Mat4::from_rows(body_m), faces, body);
+    o.meshes.push_back(std::move(lid));
+    o.meshes.push_back(std::move(body));
+    uint32_t length = (uint32_t)o.textures.size();
+    o.textures.push_back(Texture::new_solid_color(V(0.9, 0.9, 0.9)));
+    o.textures.push_back(Texture::new_solid_color(white()));
+    o.materials.push_back(Material::make_plastic(length, length + 1, 0, 0.00001, true));
+    uint32_t len = (uint32_t)o.textures.size();
+    o.textures.push_back(Texture::new_solid_color(scale(white(), 0.2)));
+    o.textures.push_back(Texture::new_solid_color(V(0.325, 0.31, 0.325)));
+    o.textures.push_back(Texture::new_solid_color(V(0.725, 0.71, 0.68)));
+    o.textures.push_back(Texture::new_checkered(len + 1, len + 2, 10.));
+    o.materials.push_back(Material::make_matte(len, 0., 0));
+    o.materials.push_back(Material::make_matte(len + 3, 0., 0));
+    for (auto& t : generate_triangles(o.meshes, 0, 0)) o.objs.push_back(t);
+    for (auto& t : generate_triangles(o.meshes, 1, 0)) o.objs.push_back(t);
+    o.objs.push_back(Primitive::new_xy_rect_transform(-1., -1., 1., 1., 0., 2, &floor_transform));
+    out.camera = camera;
+    out.name = "teapot_hdr.png";
+    out.build(std::move(o));
+    return true;
+}
+
 bool build_preset(const std::string& name, const PresetParams& p, FlatScene& out, std::string& err) {
     if (name == "material_hdr") return material_hdr(p, out, err);
+    if (name == "teapot_hdr") return teapot_hdr(p, out, err);
     if (name == "cornell_box") return cornell_box(p, out, err);
     if (name == "cornell_box_spheres") return cornell_box_spheres(p, out, err);
     if (name == "cornell_box_statue") return cornell_box_statue(p, out, err);

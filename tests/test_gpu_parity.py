@@ -554,6 +554,41 @@ def test_environment_lit_materials_match_oracle(gpu_ctx, mat_num):
     gd.close()
 
 
+@pytest.mark.parametrize("mat_num", [1, 3])
+def test_reference_meshes_and_envmap_match_oracle(gpu_ctx, tmp_path, mat_num):
+    """Row f4 on the reference's OWN data (tests/golden/assets, tests/assets.py): data/material/models/Mesh000.obj and
+    Mesh001.obj through parse_obj (uv-mapped, with normals: the uv arm of hittable.rs:363-451 in the traversal AND the
+    shading record) under data/material/textures/envmap.hdr (1024 x 512, Distribution2D rebuilt at commit).
+    Film, counts and ray counters bit for bit; both BVH builders."""
+    from tests import assets
+    sc = rr.material_hdr(mat_num, data_dir=assets.material_dir(tmp_path), mesh_faces=4000)
+    d = sc.desc.contents
+    assert d.meshes[0].n_ind // 3 == 17536 and d.meshes[0].n_uv > 0 and d.textures[0].width == 1024
+    cfg = rr.make_cfg(72, 64, 8, seed=9)
+    ro, no, so = O.OracleScene(sc).render(sc.camera, cfg, O.ORDERED, 16)
+    for dev_build in (False, True):
+        gs = gpu_ctx.upload(sc, device_build=dev_build)
+        rg, ng, sg = gpu_ctx.render(gs, sc.camera, cfg)
+        assert np.array_equal(ng, no) and rmse(rg, ng, ro, no) < RMSE_TOL
+        assert np.array_equal(rg, ro)
+        assert (sg.rays_extension, sg.rays_shadow, sg.rays_probe, sg.vertices_shaded) == \
+               (so.rays_extension, so.rays_shadow, so.rays_probe, so.vertices_shaded)
+        gs.close()
+    assert ro.mean() > 0.01
+
+
+def test_teapot_hdr_matches_oracle(gpu_ctx):
+    """scenes.rs:744-808 teapot_hdr(): smooth plastic (two lobes, alpha clamped at 1e-3) under the environment light."""
+    sc = rr.teapot_hdr(16 / 9, mesh_faces=6000)
+    cfg = rr.make_cfg(64, 36, 8, seed=4)
+    ro, no, so = O.OracleScene(sc).render(sc.camera, cfg)
+    gs = gpu_ctx.upload(sc)
+    rg, ng, sg = gpu_ctx.render(gs, sc.camera, cfg)
+    assert np.array_equal(rg, ro) and np.array_equal(ng, no)
+    assert (sg.rays_extension, sg.rays_shadow, sg.rays_probe) == (so.rays_extension, so.rays_shadow, so.rays_probe)
+    gs.close()
+
+
 def test_rough_glass_in_the_cornell_box(gpu_ctx):
     """Rough dielectric under an AREA light: the kernels compiled with the f4 features also carry the old paths."""
     from tests import oracle_ffi

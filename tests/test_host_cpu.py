@@ -416,3 +416,51 @@ def test_png_writer_round_trip(tmp_path):
         assert np.array_equal(_read_png(p), img)
     with pytest.raises(Exception):
         rr.write_png(tmp_path / "no_such_dir" / "x.png", img)
+
+
+def test_teapot_hdr_preset():
+    """scenes.rs:744-808 teapot_hdr(): camera, one plastic material (roughness 1e-5, remapped) on two meshes, the
+    checkered matte floor rect with its transform, the infinite light on texture 0."""
+    sc = rr.teapot_hdr(16 / 9, mesh_faces=4000)
+    d = sc.desc.contents
+    assert sc.name == "teapot_hdr.png"
+    assert d.n_meshes == 2 and d.n_lights == 1 and d.lights[0].kind == 1 and d.lights[0].tex_index == 0
+    assert d.n_prims == 4000 + 4000 // 8 + 1
+    assert d.n_textures == 1 + 2 + 4 and d.n_materials == 3
+    m = d.materials[0]
+    assert m.kind == 2 and m.f[0] == 0.00001 and m.remap_roughness == 1          # make_plastic(.., 0.00001, true)
+    assert [d.prims[i].mat_index for i in (0, 4000 // 8, d.n_prims - 1)] == [0, 0, 2]
+    fl = d.prims[d.n_prims - 1]
+    assert fl.kind == 2 and fl.xform_index >= 0 and tuple(fl.v[:5]) == (-1.0, -1.0, 1.0, 1.0, 0.0)
+    assert d.textures[6].kind == 1 and (d.textures[6].even, d.textures[6].odd) == (4, 5) and d.textures[6].frequency == 10.0  # new_checkered(even, odd, f), material.rs:621
+    cam = sc.camera.contents
+    assert tuple(cam.origin) == (23.895, 11.2207, 0.0400773) and cam.lens_radius == 0.0
+    # the oracle renders it (environment-lit plastic): finite, and the teapot darkens the middle of the frame
+    from tests import oracle_ffi as O
+    r, n, s = O.OracleScene(sc).render(sc.camera, rr.make_cfg(48, 27, 4, seed=2))
+    assert np.isfinite(r).all() and s.rays > 48 * 27 * 4
+
+
+def test_committed_reference_assets_round_trip(tmp_path):
+    """tests/golden/assets: the reference's Mesh000/001.obj and envmap.hdr as committed fixtures (tests/assets.py) go
+    through parse_obj / Texture::new_hdr exactly like the files of the checkout."""
+    from tests import assets
+    root = assets.material_dir(tmp_path)
+    sc = rr.material_hdr(1, data_dir=root, mesh_faces=2000)
+    d = sc.desc.contents
+    assert d.n_meshes == 3
+    # Mesh001.obj: 17536 faces / 35072 vertices with normals and uvs; Mesh000.obj: 13312 / 26624; Mesh002 = stand-in
+    assert (d.meshes[0].n_ind // 3, d.meshes[0].n_p, d.meshes[0].n_n, d.meshes[0].n_uv) == (17536, 35072, 35072, 35072)
+    assert (d.meshes[2].n_ind // 3, d.meshes[2].n_p) == (13312, 26624)
+    assert d.meshes[1].n_ind // 3 == 2000 and d.meshes[1].n_uv == 0
+    assert (d.textures[0].width, d.textures[0].height) == (1024, 512)
+    if os.path.exists("/root/reference/data/material/models/Mesh000.obj"):   # build container: identical to the checkout
+        sc_ref = rr.material_hdr(1, data_dir="/root/reference/data/material", mesh_faces=2000)
+        dr = sc_ref.desc.contents
+        for k in (0, 2):
+            a = np.ctypeslib.as_array(d.meshes[k].p, shape=(d.meshes[k].n_p, 3))
+            b = np.ctypeslib.as_array(dr.meshes[k].p, shape=(dr.meshes[k].n_p, 3))
+            assert np.array_equal(a, b)
+        ta = np.ctypeslib.as_array(d.textures[0].rgbe, shape=(512, 1024, 4))
+        tb = np.ctypeslib.as_array(dr.textures[0].rgbe, shape=(512, 1024, 4))
+        assert np.array_equal(ta, tb)

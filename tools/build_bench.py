@@ -15,7 +15,11 @@ out = []
 for name, make, W, H, spp in CASES:
     sc = make()
     row = {"scene": name}
-    for label, dev in (("host_sah", False), ("device_lbvh", True)):
+    # device builder: plain Morton-order tree, and with 1 / 2 / 3 refit passes that apply tree rotations (bvh_gpu.hip)
+    for label, dev, rot in (("host_sah", False, None), ("device_lbvh_rot0", True, 0), ("device_lbvh_rot1", True, 1),
+                            ("device_lbvh", True, 2), ("device_lbvh_rot3", True, 3)):
+        if rot is not None:
+            os.environ["RT_LBVH_ROTATE_PASSES"] = str(rot)
         t0 = time.time()
         gs = ctx.upload(sc, device_build=dev)
         wall = (time.time() - t0) * 1e3
@@ -31,6 +35,10 @@ for name, make, W, H, spp in CASES:
                       "Mrays_s": st.rays / dt / 1e6, "trace_ms": st.trace_ms, "kernel_ms": st.kernel_ms,
                       "nodes_per_ray": stc.nodes_fetched / stc.rays, "tris_per_ray": stc.tris_tested / stc.rays}
         gs.close()
+    for k in row:
+        if k.startswith("device"):
+            row[k]["nodes_per_ray_vs_host"] = row[k]["nodes_per_ray"] / row["host_sah"]["nodes_per_ray"]
+            row[k]["trace_ms_vs_host"] = row[k]["trace_ms"] / row["host_sah"]["trace_ms"]
     out.append(row)
     print(json.dumps(row), flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
