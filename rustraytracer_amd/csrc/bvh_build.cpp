@@ -567,6 +567,47 @@ void build_bvh8(const rt_primitive* prims, size_t n, Bvh8Out& out) {
     }
 }
 
+void build_sah_binary(const double* boxes, size_t n, std::vector<int32_t>& left, std::vector<int32_t>& right) {
+    left.assign(n > 1 ? n - 1 : 0, 0);
+    right.assign(n > 1 ? n - 1 : 0, 0);
+    if (n < 2) return;
+    // the builder reads only a primitive's box and kind
+    std::vector<rt_primitive> fake(n);
+    std::memset(fake.data(), 0, n * sizeof(rt_primitive));
+    for (size_t i = 0; i < n; i++) {
+        fake[i].kind = RT_PRIM_TRIANGLE;
+        for (int a = 0; a < 3; a++) {
+            fake[i].bbox_min[a] = boxes[i * 6 + a];
+            fake[i].bbox_max[a] = boxes[i * 6 + 3 + a];
+        }
+    }
+    Builder bd(fake.data(), n);
+    bd.max_leaf = 1;
+    const int32_t root = bd.build(0, n, 0);  // serial: a few thousand boxes
+    // number the internal nodes depth-first from the root
+    std::vector<int32_t> id(bd.bin.size(), -1);
+    int32_t next = 0;
+    std::vector<int32_t> stack{root};
+    while (!stack.empty()) {
+        const int32_t b = stack.back();
+        stack.pop_back();
+        if (bd.bin[b].is_leaf) continue;
+        id[b] = next++;
+        stack.push_back(bd.bin[b].right);
+        stack.push_back(bd.bin[b].left);
+    }
+    auto ref = [&](int32_t b) -> int32_t {
+        if (!bd.bin[b].is_leaf) return id[b];
+        const uint32_t code = (uint32_t)(-1 - bd.bin[b].leaf_ref);
+        return ~(int32_t)bd.order[(code & ~kLeafCodeOther) >> 3];
+    };
+    for (size_t b = 0; b < bd.bin.size(); b++)
+        if (id[b] >= 0) {
+            left[id[b]] = ref(bd.bin[b].left);
+            right[id[b]] = ref(bd.bin[b].right);
+        }
+}
+
 void build_bvh(const rt_primitive* prims, size_t n, BvhOut& out) {
     out.nodes.clear();
     out.order.clear();

@@ -20,6 +20,7 @@ struct DeviceBvh {
     uint64_t n_triangles = 0;
     float build_ms = 0.0f;         // device time of the whole build (HIP events)
     uint32_t rotation_passes = 0;  // refit passes that applied tree rotations (0: plain Morton-order tree)
+    uint32_t sah_top_clusters = 0; // leaves of the host-built SAH top (0: the top is the Morton-order tree's own)
 };
 
 // Builds the traversal structure of `n` primitives that are already resident in HBM (`d_prims`, with the

@@ -20,7 +20,9 @@
 //
 // Everything runs on one stream; the host only reads back the per-level queue length.
 #include "bvh_gpu.h"
+#include "bvh_build.h"
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -436,6 +438,44 @@ __global__ __launch_bounds__(256) void kb_refit(const rt_primitive* __restrict__
     }
 }
 
+// ---- SAH top (HLBVH-style): the Morton-order tree splits space at fixed bit planes, which is poor exactly where it
+// matters most -- near the root, where every ray passes.  The tree is therefore cut where subtrees get small
+// (<= `limit` primitives): the cut elements (clusters and stray single primitives) become the leaves of a binned-SAH
+// binary tree built on the HOST over a few thousand boxes (bvh_build.cpp: build_sah_binary, ~1 ms), and the radix
+// tree's own nodes above the cut -- exactly one fewer than there are cut elements -- are re-linked to that topology.
+// Below the cut the Morton order stays (plus the refit's rotations).  One primitive per leaf only (see kb_refit).
+__global__ __launch_bounds__(256) void kb_cut(const rt_primitive* __restrict__ prims, const uint32_t* __restrict__ order,
+                                              int n, Tree t, uint32_t limit, int32_t* refs, double* boxes,
+                                              int32_t* top_nodes, uint32_t* counts, uint32_t cap) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    if (t.last[i] - t.first[i] + 1u <= limit) return;  // below the cut
+    const uint32_t k = atomicAdd(&counts[1], 1u);
+    if (k < cap) top_nodes[k] = i;
+    const int32_t ch[2] = {t.left[i], t.right[i]};
+    for (int c = 0; c < 2; c++) {
+        const int32_t r = ch[c];
+        if (r >= 0 && t.last[r] - t.first[r] + 1u > limit) continue;  // another top node
+        const uint32_t k2 = atomicAdd(&counts[0], 1u);
+        if (k2 > cap) continue;  // (cap + 1 elements fit)
+        refs[k2] = r;
+        double b[6];
+        bool tri;
+        child_box(t, prims, order, r, b, tri);
+        for (int a = 0; a < 6; a++) boxes[(size_t)k2 * 6 + a] = b[a];
+    }
+}
+__global__ __launch_bounds__(256) void kb_relink(Tree t, const int32_t* __restrict__ node, const int32_t* __restrict__ nl,
+                                                 const int32_t* __restrict__ nr, uint32_t m) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const int32_t p = node[i];
+    t.left[p] = nl[i];
+    t.right[p] = nr[i];
+    set_parent(t, nl[i], p);
+    set_parent(t, nr[i], p);
+}
+
 // ---- 4-wide emission, one level per launch.  Work item = (binary node) | (4-wide node index << 32).
 __device__ inline bool leafable(const Tree& t, int32_t c) {
     return t.all_tri[c] != 0u && t.last[c] - t.first[c] + 1u <= (uint32_t)kLeafTargetPrims;
@@ -692,11 +732,67 @@ int build_bvh_device(hipStream_t stream, const rt_primitive* d_prims, const DevM
         // emission.  Rotations can deepen the tree: if the result does not fit the traversal stack, the tree is rebuilt
         // without them before giving up.
         const int rot_default = getenv("RT_LBVH_ROTATE_PASSES") ? atoi(getenv("RT_LBVH_ROTATE_PASSES")) : 2;
+        // clusters of at most this many primitives are the leaves of the host-built SAH top (0 = no SAH top)
+        const uint32_t sah_limit = getenv("RT_LBVH_SAH_CLUSTER") ? (uint32_t)atoi(getenv("RT_LBVH_SAH_CLUSTER")) : 256u;
         for (int rot_passes = rot_default;; rot_passes = 0) {
             B_TRY(hipMemsetAsync(t.flag, 0, ni * sizeof(uint32_t), stream));
             B_TRY(hipMemsetAsync(queue[0], 0, sizeof(ull), stream));  // first item: binary root 0 -> node 0
             hipLaunchKernelGGL(kb_reset_emit, dim3(1), dim3(1), 0, stream, g);
             hipLaunchKernelGGL(kb_tree, dim3(nb), dim3(256), 0, stream, skeys, (int)n, t);
+            bool sah_top_done = false;
+            if (rot_passes > 0 && kLeafTargetPrims == 1 && sah_limit > 0 && n > 4u * sah_limit) {
+                // plain refit first (the cut needs the clusters' boxes), then the SAH top, then the rotation passes
+                hipLaunchKernelGGL(kb_refit, dim3(nb), dim3(256), 0, stream, d_prims, order, (int)n, t, 0);
+                const uint32_t cap = 1u << 16;
+                int32_t *d_refs = nullptr, *d_top = nullptr;
+                double* d_boxes = nullptr;
+                uint32_t* d_counts = nullptr;
+                B_TRY(tmp.get(&d_refs, cap + 1));
+                B_TRY(tmp.get(&d_top, cap));
+                B_TRY(tmp.get(&d_boxes, (size_t)(cap + 1) * 6));
+                B_TRY(tmp.get(&d_counts, 2));
+                B_TRY(hipMemsetAsync(d_counts, 0, 2 * sizeof(uint32_t), stream));
+                hipLaunchKernelGGL(kb_cut, dim3(nb), dim3(256), 0, stream, d_prims, order, (int)n, t, sah_limit, d_refs, d_boxes,
+                                   d_top, d_counts, cap);
+                uint32_t counts[2] = {0, 0};
+                B_TRY(hipMemcpyAsync(counts, d_counts, sizeof(counts), hipMemcpyDeviceToHost, stream));
+                B_TRY(hipStreamSynchronize(stream));
+                const uint32_t n_cut = counts[0], n_top = counts[1];
+                if (n_top >= 1 && n_top <= cap && n_cut == n_top + 1) {
+                    std::vector<int32_t> refs(n_cut), top(n_top), sl, sr;
+                    std::vector<double> boxes((size_t)n_cut * 6);
+                    B_TRY(hipMemcpyAsync(refs.data(), d_refs, n_cut * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+                    B_TRY(hipMemcpyAsync(top.data(), d_top, n_top * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+                    B_TRY(hipMemcpyAsync(boxes.data(), d_boxes, boxes.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+                    B_TRY(hipStreamSynchronize(stream));
+                    build_sah_binary(boxes.data(), n_cut, sl, sr);
+                    // local node 0 is the SAH root: it takes the radix tree's root, node 0
+                    for (uint32_t k = 0; k < n_top; k++)
+                        if (top[k] == 0) {
+                            std::swap(top[k], top[0]);
+                            break;
+                        }
+                    if (top[0] == 0) {
+                        std::vector<int32_t> packed((size_t)n_top * 2);
+                        auto ref = [&](int32_t c) { return c >= 0 ? top[c] : refs[~c]; };
+                        for (uint32_t k = 0; k < n_top; k++) {
+                            packed[k] = ref(sl[k]);
+                            packed[n_top + k] = ref(sr[k]);
+                        }
+                        // (reuse the device buffers: d_top <- node ids, d_refs is too small for two arrays: the boxes buffer)
+                        int32_t* d_lr = reinterpret_cast<int32_t*>(d_boxes);
+                        B_TRY(hipMemcpyAsync(d_top, top.data(), n_top * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+                        B_TRY(hipMemcpyAsync(d_lr, packed.data(), packed.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+                        hipLaunchKernelGGL(kb_relink, dim3((n_top + 255u) / 256u), dim3(256), 0, stream, t, d_top, d_lr, d_lr + n_top,
+                                           n_top);
+                        B_TRY(hipStreamSynchronize(stream));  // the host vectors go out of scope
+                        sah_top_done = true;
+                        r.sah_top_clusters = n_cut;
+                    }
+                }
+                B_TRY(hipMemsetAsync(t.flag, 0, ni * sizeof(uint32_t), stream));
+            }
+            (void)sah_top_done;
             hipLaunchKernelGGL(kb_refit, dim3(nb), dim3(256), 0, stream, d_prims, order, (int)n, t, rot_passes > 0 ? 1 : 0);
             for (int pass = 1; pass < rot_passes; pass++) {
                 B_TRY(hipMemsetAsync(t.flag, 0, ni * sizeof(uint32_t), stream));

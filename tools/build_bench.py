@@ -16,10 +16,13 @@ for name, make, W, H, spp in CASES:
     sc = make()
     row = {"scene": name}
     # device builder: plain Morton-order tree, and with 1 / 2 / 3 refit passes that apply tree rotations (bvh_gpu.hip)
-    for label, dev, rot in (("host_sah", False, None), ("device_lbvh_rot0", True, 0), ("device_lbvh_rot1", True, 1),
-                            ("device_lbvh", True, 2), ("device_lbvh_rot3", True, 3)):
+    # also: the SAH top over clusters of <= N primitives (RT_LBVH_SAH_CLUSTER, 0 = none; default 256)
+    for label, dev, rot, sah in (("host_sah", False, None, None), ("device_lbvh_plain", True, 0, 0), ("device_lbvh_rot2", True, 2, 0),
+                                 ("device_lbvh_rot2_sah1024", True, 2, 1024), ("device_lbvh", True, 2, 256),
+                                 ("device_lbvh_rot2_sah64", True, 2, 64), ("device_lbvh_rot3_sah64", True, 3, 64)):
         if rot is not None:
             os.environ["RT_LBVH_ROTATE_PASSES"] = str(rot)
+            os.environ["RT_LBVH_SAH_CLUSTER"] = str(sah)
         t0 = time.time()
         gs = ctx.upload(sc, device_build=dev)
         wall = (time.time() - t0) * 1e3
