@@ -11,7 +11,15 @@
 #include "../../../include/rt_detmath.h"
 
 #define RTD __device__ __forceinline__
+#ifndef RT_INLINE_MATH
+#define RT_INLINE_MATH 0  // (experiment) 1: the elementary-function wrappers (ni_*, sincos2) inlined as well
+#endif
 #define RTDN __device__ __noinline__
+#if RT_INLINE_MATH
+#define RTDM __device__ __forceinline__
+#else
+#define RTDM __device__ __noinline__
+#endif
 
 // Values that stay binary64 in the f32 fast mode too: everything that lives in HBM (scene records of the ABI, path
 // state, film staging, the film).  tools/make_f32_sources.py turns every other `double` of the device sources into
@@ -42,15 +50,15 @@ RTD SinCos sincos2(double x) { return SinCos{::sinf(x), ::cosf(x)}; }
 // The elementary functions are called from dozens of sites of the shading code; inlined everywhere they blew
 // the shading kernels up to 170-290 KB of code against a 64 KB instruction cache.  One out-of-line copy each:
 #ifndef RT_INLINE_MATH
-RTDN double ni_sin(double x) { return dm_sin(x); }
-RTDN double ni_cos(double x) { return dm_cos(x); }
-RTDN double ni_atan2(double y, double x) { return dm_atan2(y, x); }
-RTDN double ni_acos(double x) { return dm_acos(x); }
-RTDN double ni_log(double x) { return dm_log(x); }
+RTDM double ni_sin(double x) { return dm_sin(x); }
+RTDM double ni_cos(double x) { return dm_cos(x); }
+RTDM double ni_atan2(double y, double x) { return dm_atan2(y, x); }
+RTDM double ni_acos(double x) { return dm_acos(x); }
+RTDM double ni_log(double x) { return dm_log(x); }
 struct SinCos {
     double s, c;
 };
-RTDN SinCos sincos2(double x) {  // == {dm_sin(x), dm_cos(x)} bit for bit, with one argument reduction (rt_detmath.h)
+RTDM SinCos sincos2(double x) {  // == {dm_sin(x), dm_cos(x)} bit for bit, with one argument reduction (rt_detmath.h)
     SinCos r;
     dm_sincos(x, &r.s, &r.c);
     return r;
@@ -100,7 +108,14 @@ RTD double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 RTD D3 cross(D3 a, D3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 RTD double norm2(D3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
 RTD double norm(D3 a) { return dm_sqrt(norm2(a)); }
+#ifndef RT_INLINE_NORMALIZE
+#define RT_INLINE_NORMALIZE 1  // normalize() inlined at its ~40 call sites of the shading kernels: k_shade -2.7 % (C4) / -3.8 % (C3) against the out-of-line call
+#endif
+#if RT_INLINE_NORMALIZE
+RTD D3 normalize(D3 a) { return a / norm(a); }
+#else
 RTDN D3 normalize(D3 a) { return a / norm(a); }
+#endif
 RTD bool is_black(D3 a) { return a.x == 0.0 && a.y == 0.0 && a.z == 0.0; }
 RTD D3 black() { return {0.0, 0.0, 0.0}; }
 RTD D3 white() { return {1.0, 1.0, 1.0}; }
