@@ -490,8 +490,14 @@ constexpr int kOvfStack = 98;  // an 8-wide node pushes up to seven children; bv
 #else
 constexpr int kOvfStack = 3 * kMaxBvhDepth + 2 - kLdsStack;  // a 4-wide node pushes up to three children
 #endif
+// BVH-node tiles staged in LDS (BASELINE north_star): every block of k_trace copies the first RT_LDS_NODES nodes -- the
+// top of the tree, which rt_scene_commit lays out breadth-first (levels 0-2 are 21 nodes) and which every ray walks --
+// into LDS once; node_step reads them with ds_read and everything else with global loads.  Round 2 measured a version
+// that went through a generic pointer (flat loads) as 11-16 % slower; that measurement was dominated by the traversal
+// stack's scratch / flat traffic (fixed in round 3).  Now: C4 k_trace -1.0 %, C3 +-0, C2 -0.3 % (profiles/
+// r03_exp_lds_nodes_two_path*.txt) -- the kernel is bound by VALU issue, not by the node fetches of its top levels.
 #ifndef RT_LDS_NODES
-#define RT_LDS_NODES 0
+#define RT_LDS_NODES 32
 #endif
 #ifndef RT_LEAF_PREFETCH
 #define RT_LEAF_PREFETCH 0  // (experiment) touch a leaf's record line when the traversal reaches the leaf, not when it is tested
@@ -505,10 +511,23 @@ struct TravStack {
     int2* lds;       // &lds_stack[threadIdx.x]; entry i at lds[i * kStackStride]
     int32_t* ovf;    // the kernel's private overflow array, kOvfStack entries
 #if RT_LDS_NODES > 0
-    const DevNode* top_nodes = nullptr;  // LDS copy of nodes[0, n_top) (k_trace only)
+    // BVH-node tiles staged in LDS (north_star): the block's copy of nodes[0, n_top), the top of the tree in breadth-first
+    // order (k_trace only; n_top = 0 elsewhere).  top_lds = its byte address in LDS.
+    uint32_t top_lds = 0;
     uint32_t n_top = 0;
 #endif
 };
+typedef const __attribute__((address_space(3))) char* LdsBytes;
+typedef float rt_v4f __attribute__((ext_vector_type(4)));
+typedef int rt_v4i __attribute__((ext_vector_type(4)));
+RTD float4 lds_ld4f(LdsBytes p) {
+    const rt_v4f v = *reinterpret_cast<const __attribute__((address_space(3))) rt_v4f*>(p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+RTD int4 lds_ld4i(LdsBytes p) {
+    const rt_v4i v = *reinterpret_cast<const __attribute__((address_space(3))) rt_v4i*>(p);
+    return make_int4(v.x, v.y, v.z, v.w);
+}
 #define RT_TRAV_STACK(ts, lds_array)            \
     int32_t ts##_ovf_store[kOvfStack];          \
     TravStack ts;                               \
@@ -668,21 +687,35 @@ template <bool COUNT>
 RTD void node_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
     // near / far plane rows of the node picked by the direction signs (rows: lo_x lo_y lo_z hi_x hi_y hi_z,
     // 16 B each), so no per-value select is needed
-#if RT_LDS_NODES > 0
-    const char* nb = (uint32_t)tv.cur < ts.n_top ? reinterpret_cast<const char*>(&ts.top_nodes[tv.cur])
-                                                   : reinterpret_cast<const char*>(&sc.nodes[tv.cur]);
-#else
-    const char* nb = reinterpret_cast<const char*>(&sc.nodes[tv.cur]);
-#endif
     const uint32_t kx = (__float_as_uint(tv.ix) >> 31) * 48u, ky = (__float_as_uint(tv.iy) >> 31) * 48u,
                    kz = (__float_as_uint(tv.iz) >> 31) * 48u;
-    const float4 nx = *reinterpret_cast<const float4*>(nb + kx);
-    const float4 ny = *reinterpret_cast<const float4*>(nb + 16u + ky);
-    const float4 nz = *reinterpret_cast<const float4*>(nb + 32u + kz);
-    const float4 fx = *reinterpret_cast<const float4*>(nb + 48u - kx);
-    const float4 fy = *reinterpret_cast<const float4*>(nb + 64u - ky);
-    const float4 fz = *reinterpret_cast<const float4*>(nb + 80u - kz);
-    const int4 ch = *reinterpret_cast<const int4*>(nb + 96u);
+    float4 nx, ny, nz, fx, fy, fz;
+    int4 ch;
+#if RT_LDS_NODES > 0
+    // Two separately addressed paths -- ds_read for the lanes in the staged top of the tree, global loads for the
+    // others -- into the same registers (a generic pointer would make all of them flat loads, which occupy both the
+    // LDS and the vector-memory path and both wait counters).
+    if ((uint32_t)tv.cur < ts.n_top) {
+        const LdsBytes lb = (LdsBytes)(uintptr_t)(ts.top_lds + (uint32_t)tv.cur * 128u);
+        nx = lds_ld4f(lb + kx);
+        ny = lds_ld4f(lb + 16u + ky);
+        nz = lds_ld4f(lb + 32u + kz);
+        fx = lds_ld4f(lb + 48u - kx);
+        fy = lds_ld4f(lb + 64u - ky);
+        fz = lds_ld4f(lb + 80u - kz);
+        ch = lds_ld4i(lb + 96u);
+    } else
+#endif
+    {
+        const char* nb = reinterpret_cast<const char*>(&sc.nodes[tv.cur]);
+        nx = *reinterpret_cast<const float4*>(nb + kx);
+        ny = *reinterpret_cast<const float4*>(nb + 16u + ky);
+        nz = *reinterpret_cast<const float4*>(nb + 32u + kz);
+        fx = *reinterpret_cast<const float4*>(nb + 48u - kx);
+        fy = *reinterpret_cast<const float4*>(nb + 64u - ky);
+        fz = *reinterpret_cast<const float4*>(nb + 80u - kz);
+        ch = *reinterpret_cast<const int4*>(nb + 96u);
+    }
     if (COUNT) tc->nodes++;
     const float tmin32 = float_lower(tv.tmin);
     const float tmax32 = (float)tv.tmax * (1.0f + kNodeSlack);

@@ -236,9 +236,9 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
     __shared__ int2 lds_stack[kLdsStack * 256];
     RT_TRAV_STACK(ts, lds_stack)
 #if RT_LDS_NODES > 0
-    // (experiment, BASELINE north_star: "BVH-node tiles staged in LDS") the first RT_LDS_NODES nodes -- the top of the
-    // tree, which rt_scene_commit lays out breadth-first -- are copied into LDS once per block; node_step fetches
-    // them through a generic pointer (one flat load serves both the LDS and the HBM lanes of a round)
+    // BASELINE north_star: "BVH-node tiles staged in LDS" -- the first RT_LDS_NODES nodes, the top of the tree, which
+    // rt_scene_commit lays out breadth-first, are copied into LDS once per block; node_step reads them with ds_read
+    // (geom.h), the rest of the tree with global loads
     __shared__ DevNode lds_nodes[RT_LDS_NODES];
     {
         const uint32_t n_top = sc.n_nodes < (uint32_t)RT_LDS_NODES ? sc.n_nodes : (uint32_t)RT_LDS_NODES;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
         float4* dst = reinterpret_cast<float4*>(lds_nodes);
         for (uint32_t i = threadIdx.x; i < n_top * 8u; i += 256u) dst[i] = src[i];
         __syncthreads();
-        ts.top_nodes = lds_nodes;
+        ts.top_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_nodes;  // C-style: the address-space cast
         ts.n_top = n_top;
     }
 #endif
