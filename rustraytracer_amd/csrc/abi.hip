@@ -672,6 +672,15 @@ static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cac
         if ((rc = upload(t, dtex.data(), dtex.size(), &d.texs)) != RT_OK) return rc;
     }
     if ((rc = upload(t, s->lights.data(), s->lights.size(), &d.lights)) != RT_OK) return rc;
+    {   // scene_dev.h: light_prims
+        std::vector<rt_primitive> lp(s->lights.size());
+        std::memset(lp.data(), 0, lp.size() * sizeof(rt_primitive));
+        for (size_t i = 0; i < lp.size(); i++)
+            if (s->lights[i].kind == RT_LIGHT_DIFFUSE) lp[i] = s->prims[s->lights[i].prim_index];
+        if ((rc = upload(t, lp.data(), lp.size(), &d.light_prims)) != RT_OK) return rc;
+    }
+    d.n_mats = (uint32_t)s->mats.size();
+    d.n_texs = (uint32_t)s->texs.size();
     d.env.light = -1;
     int need = 0;  // shading.h: kFeat*
     for (const rt_material& m : s->mats) {

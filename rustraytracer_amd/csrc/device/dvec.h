@@ -123,9 +123,19 @@ RTD double comp(D3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 
 // RNG block of include/rt_abi.h
 RTD uint64_t rng_mix(uint64_t z) {
+#ifdef RT_RNG_COST_EXPERIMENT
+    // (measurement only, breaks parity: what the two 64-bit multiplications of the finaliser cost -- a multiply-free
+    // xorshift scramble instead)
+    z ^= z >> 30;
+    z ^= z << 21;
+    z ^= z >> 27;
+    z ^= z << 13;
+    return z ^ (z >> 31);
+#else
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
+#endif
 }
 RTD uint64_t rng_init(uint64_t seed, uint64_t pixel, uint64_t sample) {
     return rng_mix(rng_mix(seed * RT_RNG_G + pixel) + sample * RT_RNG_H + RT_RNG_J);

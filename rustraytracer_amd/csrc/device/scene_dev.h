@@ -116,6 +116,10 @@ struct DevScene {
     const DevMat* mats;
     const rt_texture* texs;
     const rt_light* lights;
+    // (round 3) the primitive record of every light, in light order (lights[i].prim_index's record; zeros for the
+    // infinite light): with n_mats / n_texs it lets the shading kernels stage the scene's small tables in LDS
+    const rt_primitive* light_prims;
+    uint32_t n_mats, n_texs;
     uint32_t n_prims, n_lights, n_nodes, mesh_has_uv;  // mesh_has_uv: any mesh carries uvs
     uint32_t simple_others, pad_so;                   // no sphere and no transformed rect in the scene
     DevEnv env;
