@@ -44,7 +44,8 @@ for case in range(n_cases):
     # round 3: a third of the cases through the lens arm of Camera::get_ray (geometry.rs:177-190): the preset's camera
     # with lens_radius > 0 (the frame u, v and the focus plane stay the preset's)
     cam = F.rt_camera()
-    C.memmove(C.byref(cam), sc.camera, C.sizeof(cam))
+    src = sc.camera  # a pointer for the host presets, a struct for the tests' scene builder
+    C.memmove(C.byref(cam), src if isinstance(src, C._Pointer) else C.byref(src), C.sizeof(cam))
     lens = float(rng.choice([0.0, 0.0, 0.08, 2.5]))
     cam.lens_radius = lens
     acc = nacc = None

@@ -1,10 +1,14 @@
 #!/bin/bash
-# end-of-round evidence: refreshed profiles for c4 / c3 / c2, the default bench line, the 2-rank gloo dry run
+# On the GPU box: everything profiles/ is built from at the end of a round.  usage: tools/gpu_final.sh rNN
+R=${1:-r03}
 mkdir -p gpurun_out
-for tag in c4 c3 c2; do
-  timeout 1500 bash tools/refresh_profiles.sh $tag > gpurun_out/refresh_$tag.log 2>&1
-  tail -c 200 gpurun_out/refresh_$tag.log; echo
+timeout 1800 python -m pytest tests -q -m gpu > gpurun_out/${R}_gputests.log 2>&1; echo "tests rc=$?"; tail -2 gpurun_out/${R}_gputests.log
+for wl in c4 c3 c2; do bash tools/refresh_profiles.sh $wl > gpurun_out/${R}_refresh_$wl.log 2>&1; echo "refresh $wl rc=$?"; done
+python bench.py > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.err; echo "default bench rc=$?"
+for wl in c5 c3p hdr hdr1 teapot; do
+  extra=""; [ $wl = c5 ] && extra="--steps 1 --warmup 0"
+  python bench.py --workload $wl --no-cpu-baseline --no-extra $extra > gpurun_out/${R}_bench_$wl.json 2> gpurun_out/${R}_bench_$wl.err; echo "bench $wl rc=$?"
 done
-( timeout 1200 python bench.py > gpurun_out/r02_bench_default.json 2> gpurun_out/r02_bench_default.err; echo "rc=$?" >> gpurun_out/r02_bench_default.err )
-( timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --backend gloo --workload c3 --steps 2 --warmup 1 > gpurun_out/r02_bench_c3_2ranks_gloo.json 2> gpurun_out/r02_bench_c3_2ranks_gloo.err; echo "rc=$?" >> gpurun_out/r02_bench_c3_2ranks_gloo.err )
-tail -c 300 gpurun_out/r02_bench_default.json; echo; tail -2 gpurun_out/r02_bench_default.err; tail -c 300 gpurun_out/r02_bench_c3_2ranks_gloo.json
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --backend gloo --workload c3 --steps 2 --warmup 1 > gpurun_out/${R}_bench_c3_2ranks_gloo_one_gpu.json 2> gpurun_out/${R}_bench_2ranks.err; echo "2-rank gloo bench rc=$?"
+python tools/fuzz_parity.py 400 3003 > gpurun_out/${R}_fuzz_parity_400_seed3003.txt 2>&1; echo "fuzz rc=$?"; tail -1 gpurun_out/${R}_fuzz_parity_400_seed3003.txt
+{ python tools/bigparity.py cornell_box_statue 400000 512 64 0; python tools/bigparity.py plastic_dragon 871414 512 32 1; } > gpurun_out/${R}_bigparity.txt 2>&1; echo "bigparity rc=$?"; grep -E "pixels differing|rmse" gpurun_out/${R}_bigparity.txt
