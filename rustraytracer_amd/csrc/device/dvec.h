@@ -11,15 +11,7 @@
 #include "../../../include/rt_detmath.h"
 
 #define RTD __device__ __forceinline__
-#ifndef RT_INLINE_MATH
-#define RT_INLINE_MATH 0  // (experiment) 1: the elementary-function wrappers (ni_*, sincos2) inlined as well
-#endif
 #define RTDN __device__ __noinline__
-#if RT_INLINE_MATH
-#define RTDM __device__ __forceinline__
-#else
-#define RTDM __device__ __noinline__
-#endif
 
 // Values that stay binary64 in the f32 fast mode too: everything that lives in HBM (scene records of the ABI, path
 // state, film staging, the film).  tools/make_f32_sources.py turns every other `double` of the device sources into
@@ -50,15 +42,15 @@ RTD SinCos sincos2(double x) { return SinCos{::sinf(x), ::cosf(x)}; }
 // The elementary functions are called from dozens of sites of the shading code; inlined everywhere they blew
 // the shading kernels up to 170-290 KB of code against a 64 KB instruction cache.  One out-of-line copy each:
 #ifndef RT_INLINE_MATH
-RTDM double ni_sin(double x) { return dm_sin(x); }
-RTDM double ni_cos(double x) { return dm_cos(x); }
-RTDM double ni_atan2(double y, double x) { return dm_atan2(y, x); }
-RTDM double ni_acos(double x) { return dm_acos(x); }
-RTDM double ni_log(double x) { return dm_log(x); }
+RTDN double ni_sin(double x) { return dm_sin(x); }
+RTDN double ni_cos(double x) { return dm_cos(x); }
+RTDN double ni_atan2(double y, double x) { return dm_atan2(y, x); }
+RTDN double ni_acos(double x) { return dm_acos(x); }
+RTDN double ni_log(double x) { return dm_log(x); }
 struct SinCos {
     double s, c;
 };
-RTDM SinCos sincos2(double x) {  // == {dm_sin(x), dm_cos(x)} bit for bit, with one argument reduction (rt_detmath.h)
+RTDN SinCos sincos2(double x) {  // == {dm_sin(x), dm_cos(x)} bit for bit, with one argument reduction (rt_detmath.h)
     SinCos r;
     dm_sincos(x, &r.s, &r.c);
     return r;
@@ -108,14 +100,9 @@ RTD double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 RTD D3 cross(D3 a, D3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 RTD double norm2(D3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
 RTD double norm(D3 a) { return dm_sqrt(norm2(a)); }
-#ifndef RT_INLINE_NORMALIZE
-#define RT_INLINE_NORMALIZE 1  // normalize() inlined at its ~40 call sites of the shading kernels: k_shade -2.7 % (C4) / -3.8 % (C3) against the out-of-line call
-#endif
-#if RT_INLINE_NORMALIZE
+// (inlined at its ~40 call sites in the shading kernels: the out-of-line call of rounds 1-2 -- chosen for code size -- cost
+// k_shade 2-4 %, profiles/r03_exp_inline_normalize.txt; the elementary-function wrappers above stay out of line: no gain)
 RTD D3 normalize(D3 a) { return a / norm(a); }
-#else
-RTDN D3 normalize(D3 a) { return a / norm(a); }
-#endif
 RTD bool is_black(D3 a) { return a.x == 0.0 && a.y == 0.0 && a.z == 0.0; }
 RTD D3 black() { return {0.0, 0.0, 0.0}; }
 RTD D3 white() { return {1.0, 1.0, 1.0}; }
@@ -123,19 +110,9 @@ RTD double comp(D3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 
 // RNG block of include/rt_abi.h
 RTD uint64_t rng_mix(uint64_t z) {
-#ifdef RT_RNG_COST_EXPERIMENT
-    // (measurement only, breaks parity: what the two 64-bit multiplications of the finaliser cost -- a multiply-free
-    // xorshift scramble instead)
-    z ^= z >> 30;
-    z ^= z << 21;
-    z ^= z >> 27;
-    z ^= z << 13;
-    return z ^ (z >> 31);
-#else
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
-#endif
 }
 RTD uint64_t rng_init(uint64_t seed, uint64_t pixel, uint64_t sample) {
     return rng_mix(rng_mix(seed * RT_RNG_G + pixel) + sample * RT_RNG_H + RT_RNG_J);

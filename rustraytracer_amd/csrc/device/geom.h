@@ -499,12 +499,6 @@ constexpr int kOvfStack = 3 * kMaxBvhDepth + 2 - kLdsStack;  // a 4-wide node pu
 #ifndef RT_LDS_NODES
 #define RT_LDS_NODES 32
 #endif
-#ifndef RT_LEAF_PREFETCH
-#define RT_LEAF_PREFETCH 0  // (experiment) touch a leaf's record line when the traversal reaches the leaf, not when it is tested
-#endif
-#ifndef RT_CACHE_F32_BOUNDS
-#define RT_CACHE_F32_BOUNDS 0  // (experiment) node_step's tmin32 / lim32 kept per ray instead of recomputed per node
-#endif
 // (Round 3) The struct holds two POINTERS and nothing else, so that it lives in registers: with the overflow array inside it
 // the whole struct sat in scratch, and every push / pop first re-read the LDS base and the stride from scratch
 // (scratch_load + s_waitcnt vmcnt(0) + a quarter-rate v_mul_lo_u32 per stack access), and the pop loop read its entries
@@ -572,12 +566,6 @@ struct Trav {
     uint32_t best_slot;  // leaf slot of best_prim (| kLeafOther)
     int sp;
     bool done;
-#if RT_LEAF_PREFETCH
-    uint32_t pf;  // the leaf_prim word of the leaf `cur` points at, fetched when the leaf was reached (leaf_touch)
-#endif
-#if RT_CACHE_F32_BOUNDS
-    float tmin32, lim32;  // node_step's f32 interval bounds: per ray / updated when the best hit changes (trav_bounds)
-#endif
 };
 
 
@@ -610,7 +598,6 @@ RTD void node_consts(Trav& tv, D3 o, D3 inv) {
     tv.cfz = (float)(-oz + sz);
 }
 
-RTD void trav_bounds(Trav& tv);
 RTD void trav_init(Trav& tv, const DevScene& sc, D3 o, D3 dir, double tmin, double tmax) {
 #ifdef RT_F32
     // Fast mode only.  In binary32 a direction component is EXACTLY zero every few hundred thousand rays (e.g.
@@ -641,7 +628,6 @@ RTD void trav_init(Trav& tv, const DevScene& sc, D3 o, D3 dir, double tmin, doub
     // triangle is visited first, i.e. the reference's answer depends on its random tree.  The ABI pins it:
     // such a ray misses.
     tv.done = (o.x != o.x) || (o.y != o.y) || (o.z != o.z) || (dir.x != dir.x) || (dir.y != dir.y) || (dir.z != dir.z);
-    trav_bounds(tv);
 }
 
 // Upper end of the interval a subtree's box must overlap to be worth visiting.  A triangle hit may lie
@@ -652,13 +638,6 @@ RTD void trav_init(Trav& tv, const DevScene& sc, D3 o, D3 dir, double tmin, doub
 RTD double prune_limit(const Trav& tv) {
     if (tv.best_prim < 0) return tv.tmax;
     return hmax(tv.best_t * (1.0 + 1e-9), tv.tmin * (1.0 + 1e-9) + 1e-300);
-}
-
-RTD void trav_bounds(Trav& tv) {
-#if RT_CACHE_F32_BOUNDS
-    tv.tmin32 = float_lower(tv.tmin);
-    tv.lim32 = (float)prune_limit(tv) * (1.0f + kNodeSlack);
-#endif
 }
 
 // pop the next subtree that can still contain a closer hit; marks the traversal done when none is left
@@ -675,24 +654,6 @@ RTD void trav_pop(Trav& tv, TravStack& ts) {
         }
     }
     tv.done = true;
-}
-
-// (experiment RT_LEAF_PREFETCH) A lane that has just reached a leaf usually waits a round or more for the wave's next
-// primitive round (majority scheduling).  Fetching the leaf record's index word right away -- the one word of the
-// record that does not depend on the ray -- starts the line on its way to L1 during that wait, and leaf_step has one
-// load less to issue.  Loads return in order, so the older fetch never delays the round that follows.
-RTD void leaf_touch(Trav& tv, const DevScene& sc) {
-#if RT_LEAF_PREFETCH
-    if (!tv.done && tv.cur < 0) {
-        const uint32_t code = (uint32_t)(-1 - tv.cur);
-        const uint32_t slot = (code & ~kLeafCodeOther) >> 3;
-#ifdef RT_F32
-        tv.pf = sc.leaf_prim[slot];
-#else
-        tv.pf = reinterpret_cast<const uint32_t*>(sc.leaf_trav + (size_t)slot * 16)[30];
-#endif
-    }
-#endif
 }
 
 // One internal node: test its four children (one 128-B fetch), descend into the nearest hit and push
@@ -732,13 +693,9 @@ RTD void node_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
         ch = *reinterpret_cast<const int4*>(nb + 96u);
     }
     if (COUNT) tc->nodes++;
-#if RT_CACHE_F32_BOUNDS
-    const float tmin32 = tv.tmin32, lim32 = tv.lim32;
-#else
     const float tmin32 = float_lower(tv.tmin);
-    const float lim32 = (float)prune_limit(tv) * (1.0f + kNodeSlack);
-#endif
     const float tmax32 = (float)tv.tmax * (1.0f + kNodeSlack);
+    const float lim32 = (float)prune_limit(tv) * (1.0f + kNodeSlack);
 #define RT_NODE_CHILD(c, e, h, cid)                                                                    \
     float e;                                                                                           \
     bool h;                                                                                            \
@@ -914,20 +871,12 @@ RTD void leaf_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
     const uint32_t first = (code & ~kLeafCodeOther) >> 3, count = (code & 7u) + 1u;
     const uint32_t slot = first;
 #ifdef RT_F32
-#if RT_LEAF_PREFETCH
-    const uint32_t e = tv.pf;
-#else
     const uint32_t e = sc.leaf_prim[slot];
-#endif
     const float* tvp = sc.leaf_tri32 + (size_t)slot * 9;  // RT_KEEP_F64
 #else
     // one aligned 128-B line per slot (scene_dev.h: leaf_trav): geometry and the primitive index word
     const f64_t* rec = sc.leaf_trav + (size_t)slot * 16;
-#if RT_LEAF_PREFETCH
-    const uint32_t e = tv.pf;
-#else
     const uint32_t e = reinterpret_cast<const uint32_t*>(rec)[30];
-#endif
 #endif
     double t = 0.0;
     int32_t pi = -1;
@@ -1044,7 +993,6 @@ RTD void leaf_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
         tv.best_t = t;
         tv.best_prim = pi;
         tv.best_slot = slot | (e & kLeafOther);
-        trav_bounds(tv);
     }
     // the rest of the leaf is the leaf (first + 1, count - 1): no separate cursor to keep in a register
     if (count > 1u)
@@ -1068,7 +1016,6 @@ RTD int32_t closest_hit(const DevScene& sc, D3 o, D3 dir, double tmin, double tm
             node_step<COUNT>(tv, sc, ts, tc);
         else
             leaf_step<COUNT>(tv, sc, ts, tc);
-        leaf_touch(tv, sc);
     }
     t_out = tv.best_t;
     if (slot_out) *slot_out = tv.best_slot;

@@ -382,19 +382,13 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
                 diag_rounds[0]++;
                 diag_rounds[1] += (uint32_t)cn;
             }
-            if (at_node) {
-                node_step<COUNT>(tv, sc, ts, &tc);
-                leaf_touch(tv, sc);
-            }
+            if (at_node) node_step<COUNT>(tv, sc, ts, &tc);
         } else if (cl > 0) {
             if (COUNT) {  // diagnostic: lanes busy per primitive round
                 diag_rounds[2]++;
                 diag_rounds[3] += (uint32_t)cl;
             }
-            if (at_leaf) {
-                leaf_step<COUNT, SIMPLE>(tv, sc, ts, &tc);
-                leaf_touch(tv, sc);
-            }
+            if (at_leaf) leaf_step<COUNT, SIMPLE>(tv, sc, ts, &tc);
         }
         if (has_ray && tv.done) {
             if (COUNT) {  // diagnostic: longest traversal, and how many rays needed more than 64 / 256 steps
@@ -492,48 +486,6 @@ struct ShadeProf {
 #define RT_PROF(k)
 #define RT_PROF_FLUSH
 #endif
-
-// ---- the scene's small tables staged in LDS (round 3)
-// A shaded vertex walks a chain of DEPENDENT lookups into tables of a few entries -- material -> texture -> checker
-// children, light -> the light's primitive -- and each link used to be a global load whose latency (an L2 hit at best:
-// the path-state streams keep evicting these lines from the vector L1) the wave had to sit out: the shading kernels
-// wait for memory 57 % of their life at 3 waves per SIMD, and making their ARITHMETIC cheaper changes nothing
-// (profiles/r03_exp_rng_cost.txt).  Every block therefore copies lights, light primitives, materials and textures into
-// LDS while its path state is on the way, and the shading code reads them there.  Scenes whose tables do not fit
-// kTabBytes keep the global pointers (block-uniform choice, so the accesses are generic loads either way).
-// RESULT (experiment, off by default): no consistent gain -- these lookups hit L2 / L1 often enough that they are
-// not what the kernel waits for.
-#ifndef RT_SHADE_LDS_TABLES
-#define RT_SHADE_LDS_TABLES 0  // measured: C2 k_shade -3 %, C3 +-0, C4 +2 %, hdr1 -1 % (profiles/r03_exp_shade_lds_tables.txt): not the bound either; off
-#endif
-constexpr uint32_t kTabBytes = 8192;
-RTD void stage_scene_tables(const DevScene& sc, DevScene& scl, unsigned char* s_tab) {
-#if RT_SHADE_LDS_TABLES
-    const uint32_t bl = sc.n_lights * (uint32_t)sizeof(rt_light), bp = sc.n_lights * (uint32_t)sizeof(rt_primitive);
-    const uint32_t bm = sc.n_mats * (uint32_t)sizeof(DevMat), bt = sc.n_texs * (uint32_t)sizeof(rt_texture);
-    static_assert(sizeof(rt_light) % 8 == 0 && sizeof(rt_primitive) % 8 == 0 && sizeof(DevMat) % 8 == 0 && sizeof(rt_texture) % 8 == 0,
-                  "tables are copied in 8-byte words");
-    if (bl + bp + bm + bt <= kTabBytes) {
-        unsigned long long* dst = reinterpret_cast<unsigned long long*>(s_tab);
-        const uint32_t wl = bl / 8u, wp = bp / 8u, wm = bm / 8u, wt = bt / 8u;
-        const unsigned long long* src[4] = {reinterpret_cast<const unsigned long long*>(sc.lights),
-                                            reinterpret_cast<const unsigned long long*>(sc.light_prims),
-                                            reinterpret_cast<const unsigned long long*>(sc.mats),
-                                            reinterpret_cast<const unsigned long long*>(sc.texs)};
-        const uint32_t cnt[4] = {wl, wp, wm, wt};
-        uint32_t base = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            for (uint32_t i = threadIdx.x; i < cnt[k]; i += blockDim.x) dst[base + i] = src[k][i];
-            base += cnt[k];
-        }
-        scl.lights = reinterpret_cast<const rt_light*>(s_tab);
-        scl.light_prims = reinterpret_cast<const rt_primitive*>(s_tab + bl);
-        scl.mats = reinterpret_cast<const DevMat*>(s_tab + bl + bp);
-        scl.texs = reinterpret_cast<const rt_texture*>(s_tab + bl + bp + bm);
-    }
-#endif
-}
 
 struct ShadeA {
     D3 L, o, d, beta;
@@ -837,11 +789,6 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc
 #define RT_SORT_FEAT0 0
 #endif
     uint32_t slot = bid * blockDim.x + threadIdx.x;
-    // the scene's small tables -> LDS (stage_scene_tables); published by the dealing step's barriers, or by the one below
-    __shared__ __attribute__((aligned(16))) unsigned char s_tab[kTabBytes];
-    DevScene scl = sc;
-    stage_scene_tables(sc, scl, s_tab);
-    if (RT_SHADE_LDS_TABLES && !(FEAT != 0 || RT_SORT_FEAT0)) __syncthreads();
     if (FEAT != 0 || RT_SORT_FEAT0) {
         constexpr uint32_t kCls = RT_SORT_CLASSES;
         __shared__ uint32_t s_cls[4][kCls];
@@ -888,7 +835,7 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc
     }
     ShadeA a;
     RT_PROF_DECL
-    shade_a<FEAT>(scl, in, slot, slot < n_active, max_depth, a RT_PROF_PASS);
+    shade_a<FEAT>(sc, in, slot, slot < n_active, max_depth, a RT_PROF_PASS);
     // a vertex that will be shaded gets its output slot now (dense, block-contiguous); if the path
     // then ends without pending light terms the slot is marked dead and skipped next bounce
     uint32_t os;
@@ -942,7 +889,7 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc
     }
     RT_PROF(8)
     ShadeOut r{false, false, false, false};
-    if (a.will_shade) r = shade_b<FEAT>(scl, in, out, slot, os, a RT_PROF_PASS);
+    if (a.will_shade) r = shade_b<FEAT>(sc, in, out, slot, os, a RT_PROF_PASS);
     if (a.live && !r.keep) {  // retired: its radiance goes to the film staging slot of (pixel, sample)
         const uint32_t og = a.orig;
         lfx[og] = a.L.x;
@@ -1084,10 +1031,6 @@ __global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathS
     __shared__ int2 lds_stack[kLdsStack * 256];
     __shared__ uint32_t s_job[4][192];  // per wave: slot of the path | ray kind << 30
     __shared__ int2 s_res[4][192];      // per wave: {prim, leaf slot} found for job j
-    __shared__ __attribute__((aligned(16))) unsigned char s_tab[kTabBytes];
-    DevScene scl = sc;
-    stage_scene_tables(sc, scl, s_tab);
-    if (RT_SHADE_LDS_TABLES) __syncthreads();
     const uint32_t ring = it_abs % kRing;
     const uint32_t n_active = ctl->n_active[ring];
     uint32_t* next_path = &ctl->head[ring];  // zero at launch: no k_trace runs in the tail iteration (k_plan cleared it)
@@ -1173,10 +1116,10 @@ __global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathS
         if (alive) {
             ShadeA a;
             RT_PROF_DECL
-            shade_a<FEAT>(scl, in, slot, true, max_depth, a RT_PROF_PASS);
+            shade_a<FEAT>(sc, in, slot, true, max_depth, a RT_PROF_PASS);
             ShadeOut r{false, false, false, false};
             if (a.will_shade) {
-                r = shade_b<FEAT>(scl, in, out, slot, slot, a RT_PROF_PASS);
+                r = shade_b<FEAT>(sc, in, out, slot, slot, a RT_PROF_PASS);
                 n_v++;
             }
             n_r1 += r.emit_ext ? 1u : 0u;

@@ -73,15 +73,7 @@ RTD D3 hdr_value(const rt_texture& t, double u, double v) {
     return d3(((double)(q & 0xffu) + 0.5) * sc / 256.0, ((double)((q >> 8) & 0xffu) + 0.5) * sc / 256.0,
               ((double)((q >> 16) & 0xffu) + 0.5) * sc / 256.0);
 }
-#ifndef RT_INLINE_TEX
-#define RT_INLINE_TEX 0
-#endif
-#if RT_INLINE_TEX
-RTD
-#else
-RTDN
-#endif
-D3 texture_value(const DevScene& sc, uint32_t index, double u, double v) {
+RTDN D3 texture_value(const DevScene& sc, uint32_t index, double u, double v) {
 #pragma unroll 1
     for (int depth = 0; depth < 8; depth++) {
         const rt_texture& t = sc.texs[index];
