@@ -479,10 +479,28 @@ static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cac
 // check is ignored and rebuilt.  Results cannot depend on it: the tree only culls (geom.h), and the file holds
 // exactly what build_bvh() returned.
 struct BvhCacheHeader {
-    char magic[8];  // "RTBVH\0\0\1"
+    char magic[8];  // "RTBVH\0\0\2"
     uint64_t key, n_prims, n_nodes;
     uint32_t depth, node_bytes;
+    uint64_t payload_sum;  // bvh_cache_sum over nodes and order: a torn or damaged file is rebuilt, not uploaded
 };
+static uint64_t bvh_cache_sum(const BvhOut& b) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    auto mix = [&](const void* p, size_t bytes) {
+        const unsigned char* c = static_cast<const unsigned char*>(p);
+        size_t i = 0;
+        for (; i + 8 <= bytes; i += 8) {
+            uint64_t w;
+            std::memcpy(&w, c + i, 8);
+            h = (h ^ w) * 0x100000001b3ull;
+            h ^= h >> 31;
+        }
+        for (; i < bytes; i++) h = (h ^ c[i]) * 0x100000001b3ull;
+    };
+    mix(b.nodes.data(), b.nodes.size() * sizeof(DevNode));
+    mix(b.order.data(), b.order.size() * sizeof(uint32_t));
+    return h;
+}
 static uint64_t bvh_cache_key(const rt_primitive* prims, size_t n) {
     uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)sizeof(DevNode) ^ ((uint64_t)kLeafTargetPrims << 32);
     const unsigned char* b = reinterpret_cast<const unsigned char*>(prims);
@@ -501,7 +519,7 @@ static bool bvh_cache_load(const std::string& path, uint64_t key, size_t np, Bvh
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) return false;
     BvhCacheHeader hd;
-    bool ok = fread(&hd, sizeof(hd), 1, f) == 1 && std::memcmp(hd.magic, "RTBVH\0\0\1", 8) == 0 && hd.key == key &&
+    bool ok = fread(&hd, sizeof(hd), 1, f) == 1 && std::memcmp(hd.magic, "RTBVH\0\0\2", 8) == 0 && hd.key == key &&
               hd.n_prims == np && hd.node_bytes == sizeof(DevNode) && hd.n_nodes > 0 && hd.n_nodes <= 2 * np + 2;
     if (ok) {
         out.nodes.resize(hd.n_nodes);
@@ -509,7 +527,20 @@ static bool bvh_cache_load(const std::string& path, uint64_t key, size_t np, Bvh
         out.depth = hd.depth;
         ok = fread(out.nodes.data(), sizeof(DevNode), hd.n_nodes, f) == hd.n_nodes &&
              fread(out.order.data(), sizeof(uint32_t), np, f) == np;
-        for (size_t i = 0; ok && i < np; i++) ok = out.order[i] < np;  // a permutation entry out of range: damaged file
+        ok = ok && bvh_cache_sum(out) == hd.payload_sum;
+        // (belt and braces: nothing the traversal would follow may point outside the arrays)
+        for (size_t i = 0; ok && i < np; i++) ok = out.order[i] < np;
+        for (size_t i = 0; ok && i < out.nodes.size(); i++)
+            for (int k = 0; ok && k < 4; k++) {
+                const int32_t c = out.nodes[i].child[k];
+                if (c == kNoChild) continue;
+                if (c >= 0)
+                    ok = (uint64_t)c < hd.n_nodes;
+                else {
+                    const uint32_t code = (uint32_t)(-1 - c) & ~kLeafCodeOther;
+                    ok = (uint64_t)(code >> 3) + (code & 7u) < np;
+                }
+            }
     }
     fclose(f);
     return ok;
@@ -519,7 +550,8 @@ static void bvh_cache_store(const std::string& path, uint64_t key, size_t np, co
     FILE* f = fopen(tmp.c_str(), "wb");
     if (!f) return;
     BvhCacheHeader hd{};
-    std::memcpy(hd.magic, "RTBVH\0\0\1", 8);
+    std::memcpy(hd.magic, "RTBVH\0\0\2", 8);
+    hd.payload_sum = bvh_cache_sum(bvh);
     hd.key = key;
     hd.n_prims = np;
     hd.n_nodes = bvh.nodes.size();

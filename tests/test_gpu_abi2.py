@@ -350,6 +350,21 @@ def test_host_bvh_is_shared_through_the_node_local_cache(gpu_ctx, tmp_path, monk
     r, n, _ = gpu_ctx.render(g4, sc.camera, cfg)
     assert np.array_equal(r, base[0])
     g4.close()
+    # ... and so is one with a flipped byte in the node array (payload checksum); the rebuild republishes a good file
+    size = os.path.getsize(files[0])
+    with open(files[0], "r+b") as fh:
+        fh.seek(size // 3)
+        b = fh.read(1)
+        fh.seek(size // 3)
+        fh.write(bytes([b[0] ^ 0x40]))
+    g4b = gpu_ctx.upload(sc)
+    assert g4b.info()["build_from_cache"] == 0
+    g4b.close()
+    g4c = gpu_ctx.upload(sc)
+    assert g4c.info()["build_from_cache"] == 1
+    r, n, _ = gpu_ctx.render(g4c, sc.camera, cfg)
+    assert np.array_equal(r, base[0])
+    g4c.close()
     # the device builder does not use it
     g5 = gpu_ctx.upload(sc, device_build=True)
     assert g5.info()["build_from_cache"] == 0
