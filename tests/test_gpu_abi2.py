@@ -369,3 +369,34 @@ def test_host_bvh_is_shared_through_the_node_local_cache(gpu_ctx, tmp_path, monk
     g5 = gpu_ctx.upload(sc, device_build=True)
     assert g5.info()["build_from_cache"] == 0
     g5.close()
+
+
+def test_plain_c_host_renders_the_same_film(gpu_ctx, tmp_path):
+    """examples/gpu_tile.c -- a host in C99 against the C ABI alone, the stand-in for the reference's Rust binding
+     -- renders the same film as the ctypes binding: byte-for-byte (FNV-1a of the film), and writes
+    the PNG of util::draw_picture."""
+    import subprocess
+    from tests.test_host_cpu import _build_c_example
+    exe = _build_c_example(tmp_path)
+    W, H, spp = 64, 48, 4
+    png = str(tmp_path / "c_host.png")
+    r = subprocess.run([exe, "cornell_box_statue", str(W), str(H), str(spp), png], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout
+    fields = r.stdout.split()
+    got = dict(zip(fields[2::2], fields[3::2]))
+
+    def fnv(buf):
+        h = 0xcbf29ce484222325
+        for b in bytes(buf):
+            h = ((h ^ b) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+        return "%016x" % h
+
+    sc = rr.Scene("cornell_box_statue", W / H, 20000, None, 0)
+    gs = gpu_ctx.upload(sc)
+    rgb, n, st = gpu_ctx.render(gs, sc.camera, rr.make_cfg(W, H, spp, seed=0))
+    gs.close()
+    assert got["film_fnv"] == fnv(rgb.tobytes()) and got["count_fnv"] == fnv(n.tobytes())
+    assert int(got["rays"]) == st.rays
+    from tests.test_host_cpu import _read_png
+    assert np.array_equal(_read_png(png), gpu_ctx.resolve_rgb8(rgb, n))
