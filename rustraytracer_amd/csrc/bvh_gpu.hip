@@ -476,6 +476,147 @@ __global__ __launch_bounds__(256) void kb_relink(Tree t, const int32_t* __restri
     set_parent(t, nr[i], p);
 }
 
+// ---- PLOC: parallel locally-ordered clustering (Meister & Bittner 2018), the device builder's optional fast topology.
+// Bottom-up agglomeration along the Morton order: every cluster looks for the neighbour within +-radius positions whose
+// union with it has the smallest surface area; mutual nearest neighbours merge into a new node; the array is compacted;
+// repeat until one cluster is left.  Unlike the radix tree it decides with AREAS, so a huge primitive (the floor)
+// simply stays unmerged until the end and hangs off the root, and clusters that straddle a Morton bit plane still find
+// each other.  Deterministic: ties go to the lower position, node numbers come from an atomic counter but the
+// topology does not depend on them.  One primitive per leaf.
+struct PlocArrays {
+    double* box;    // [count][6]
+    int32_t* ref;   // >= 0 internal node, < 0 ~sorted leaf position
+};
+__global__ __launch_bounds__(256) void kp_init(const rt_primitive* __restrict__ prims, const uint32_t* __restrict__ order,
+                                               uint32_t n, PlocArrays a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const rt_primitive& p = prims[order[i]];
+    for (int k = 0; k < 3; k++) {
+        a.box[(size_t)i * 6 + k] = p.bbox_min[k];
+        a.box[(size_t)i * 6 + 3 + k] = p.bbox_max[k];
+    }
+    a.ref[i] = ~(int32_t)i;
+}
+constexpr int kPlocMaxRadius = 64;
+__global__ __launch_bounds__(256) void kp_nearest(PlocArrays a, const uint32_t* __restrict__ count_p, int radius,
+                                                  uint32_t* nn) {
+    __shared__ double s_box[(256 + 2 * kPlocMaxRadius) * 6];
+    const uint32_t count = *count_p;
+    const int base = (int)(blockIdx.x * 256u) - radius;
+    if (blockIdx.x * 256u >= count) return;
+    const int span = 256 + 2 * radius;
+    for (int k = threadIdx.x; k < span * 6; k += 256) {
+        const int c = base + k / 6;
+        s_box[k] = (c >= 0 && (uint32_t)c < count) ? a.box[(size_t)c * 6 + k % 6] : 0.0;
+    }
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    const double* me = &s_box[(threadIdx.x + radius) * 6];
+    double best = 1e308;
+    uint32_t best_j = i;
+    for (int d = -radius; d <= radius; d++) {
+        if (d == 0) continue;
+        const long long j = (long long)i + d;
+        if (j < 0 || j >= (long long)count) continue;
+        const double ar = union_area(me, &s_box[(threadIdx.x + radius + d) * 6]);
+        if (ar < best) {  // strict: the lowest position wins a tie
+            best = ar;
+            best_j = (uint32_t)j;
+        }
+    }
+    nn[i] = best_j;
+}
+// merge mutual pairs (the lower position keeps the merged cluster, the higher one is dropped) and count survivors per block
+__global__ __launch_bounds__(256) void kp_merge(PlocArrays a, const uint32_t* __restrict__ count_p,
+                                                const uint32_t* __restrict__ nn, Tree t, const rt_primitive* __restrict__ prims,
+                                                const uint32_t* __restrict__ order, uint32_t* node_counter, uint32_t* keep,
+                                                uint32_t* block_sum) {
+    const uint32_t count = *count_p;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    uint32_t k = 0;
+    if (i < count) {
+        const uint32_t j = nn[i];
+        const bool mutual = j != i && nn[j] == i;
+        k = 1;
+        if (mutual && i > j) k = 0;
+        if (mutual && i < j) {
+            const uint32_t id = atomicAdd(node_counter, 1u);
+            const int32_t l = a.ref[i], r = a.ref[j];
+            t.left[id] = l;
+            t.right[id] = r;
+            set_parent(t, l, (int32_t)id);
+            set_parent(t, r, (int32_t)id);
+            bool tri = true;
+            for (int c = 0; c < 2; c++) {
+                const int32_t ch = c ? r : l;
+                tri = tri && (ch >= 0 ? t.all_tri[ch] != 0u : prims[order[~ch]].kind == RT_PRIM_TRIANGLE);
+            }
+            t.all_tri[id] = tri ? 1u : 0u;
+            t.first[id] = 0u;  // (ranges of sorted positions mean nothing in this tree: never "leafable", kb_emit)
+            t.last[id] = 1u;
+            for (int c = 0; c < 3; c++) {
+                const double lo = fmin(a.box[(size_t)i * 6 + c], a.box[(size_t)j * 6 + c]);
+                const double hi = fmax(a.box[(size_t)i * 6 + 3 + c], a.box[(size_t)j * 6 + 3 + c]);
+                t.box[(size_t)id * 6 + c] = lo;
+                t.box[(size_t)id * 6 + 3 + c] = hi;
+            }
+            // the merged cluster is published by kp_compact from t.box (this kernel must not overwrite a.box: the
+            // partner's thread may still be reading it)
+            keep[i] = 2u + id;  // >= 2: survivor that became node `id`
+        } else
+            keep[i] = k;
+    }
+    __shared__ uint32_t s_cnt[4];
+    const unsigned long long m = __ballot(k != 0u);
+    if ((threadIdx.x & 63u) == 0) s_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+__global__ __launch_bounds__(256) void kp_compact(PlocArrays in, PlocArrays out, uint32_t* count_p, Tree t,
+                                                  const uint32_t* __restrict__ keep, const uint32_t* __restrict__ block_off,
+                                                  uint32_t n_blocks_total) {
+    const uint32_t count = *count_p;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t kv = i < count ? keep[i] : 0u;
+    const bool k = kv != 0u;
+    __shared__ uint32_t s_cnt[4];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(k);
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t off = block_off[blockIdx.x];
+    for (uint32_t w = 0; w < wave; w++) off += s_cnt[w];
+    off += (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (k) {
+        if (kv >= 2u) {
+            const uint32_t id = kv - 2u;
+            for (int c = 0; c < 6; c++) out.box[(size_t)off * 6 + c] = t.box[(size_t)id * 6 + c];
+            out.ref[off] = (int32_t)id;
+        } else {
+            for (int c = 0; c < 6; c++) out.box[(size_t)off * 6 + c] = in.box[(size_t)i * 6 + c];
+            out.ref[off] = in.ref[i];
+        }
+    }
+    (void)n_blocks_total;
+}
+// the new count = survivors of all blocks (kb_scan has turned block_sum into exclusive offsets; `last` = the last block's own sum)
+__global__ void kp_count(uint32_t* count_p, const uint32_t* __restrict__ block_off, const uint32_t* __restrict__ last_sum,
+                         uint32_t n_blocks) {
+    *count_p = block_off[n_blocks - 1] + *last_sum;
+}
+__global__ void kp_save_last(const uint32_t* __restrict__ block_sum, uint32_t n_blocks, uint32_t* last_sum) {
+    *last_sum = block_sum[n_blocks - 1];
+}
+// the tree is complete: its root is the one cluster left; the emission queue starts there
+__global__ void kp_finish(PlocArrays a, Tree t, ull* queue0, int32_t* root_out) {
+    const int32_t root = a.ref[0];
+    t.parent[root] = -1;
+    queue0[0] = (ull)(uint32_t)root;  // binary root -> 4-wide node 0
+    *root_out = root;
+}
+
 // ---- 4-wide emission, one level per launch.  Work item = (binary node) | (4-wide node index << 32).
 __device__ inline bool leafable(const Tree& t, int32_t c) {
     return t.all_tri[c] != 0u && t.last[c] - t.first[c] + 1u <= (uint32_t)kLeafTargetPrims;
@@ -734,7 +875,87 @@ int build_bvh_device(hipStream_t stream, const rt_primitive* d_prims, const DevM
         const int rot_default = getenv("RT_LBVH_ROTATE_PASSES") ? atoi(getenv("RT_LBVH_ROTATE_PASSES")) : 2;
         // clusters of at most this many primitives are the leaves of the host-built SAH top (0 = no SAH top)
         const uint32_t sah_limit = getenv("RT_LBVH_SAH_CLUSTER") ? (uint32_t)atoi(getenv("RT_LBVH_SAH_CLUSTER")) : 256u;
-        for (int rot_passes = rot_default;; rot_passes = 0) {
+        // ---- RT_DEVICE_BUILDER=ploc: the PLOC topology instead of the Morton-order tree (the fastest build -- C4 10.6 ms
+        // against 18.8 -- at the plain Morton tree's quality: 1.18-1.20 x the host tree's node fetches, where rotations + SAH
+        // top reach 1.04-1.13 in 16-70 ms; profiles/r03_lbvh_ploc_sweep.txt).  Falls back to the default when too deep.
+        const char* which = getenv("RT_DEVICE_BUILDER");
+        bool ploc_done = false;
+        if (kLeafTargetPrims == 1 && which && std::strcmp(which, "ploc") == 0) {
+            const int radius = std::min(kPlocMaxRadius, std::max(1, getenv("RT_PLOC_RADIUS") ? atoi(getenv("RT_PLOC_RADIUS")) : 16));
+            const int ploc_rot = getenv("RT_PLOC_ROTATE_PASSES") ? atoi(getenv("RT_PLOC_ROTATE_PASSES")) : 1;
+            PlocArrays pa[2];
+            uint32_t *d_nn = nullptr, *d_keep = nullptr, *d_bsum = nullptr, *d_cnt = nullptr, *d_nodes = nullptr, *d_last = nullptr;
+            int32_t* d_root = nullptr;
+            for (int k = 0; k < 2; k++) {
+                B_TRY(tmp.get(&pa[k].box, (size_t)n * 6));
+                B_TRY(tmp.get(&pa[k].ref, n));
+            }
+            B_TRY(tmp.get(&d_nn, n));
+            B_TRY(tmp.get(&d_keep, n));
+            B_TRY(tmp.get(&d_bsum, nb + 1));
+            B_TRY(tmp.get(&d_cnt, 1));
+            B_TRY(tmp.get(&d_nodes, 1));
+            B_TRY(tmp.get(&d_last, 1));
+            B_TRY(tmp.get(&d_root, 1));
+            B_TRY(hipMemcpyAsync(d_cnt, &n, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            B_TRY(hipMemsetAsync(d_nodes, 0, sizeof(uint32_t), stream));
+            hipLaunchKernelGGL(kp_init, dim3(nb), dim3(256), 0, stream, d_prims, order, n, pa[0]);
+            uint32_t count = n;
+            int cur_a = 0, passes = 0;
+            bool stuck = false;
+            while (count > 1) {
+                const uint32_t blocks = (count + 255u) / 256u;
+                hipLaunchKernelGGL(kp_nearest, dim3(blocks), dim3(256), 0, stream, pa[cur_a], d_cnt, radius, d_nn);
+                hipLaunchKernelGGL(kp_merge, dim3(blocks), dim3(256), 0, stream, pa[cur_a], d_cnt, d_nn, t, d_prims, order, d_nodes,
+                                   d_keep, d_bsum);
+                hipLaunchKernelGGL(kp_save_last, dim3(1), dim3(1), 0, stream, d_bsum, blocks, d_last);
+                hipLaunchKernelGGL(kb_scan, dim3(1), dim3(1024), 0, stream, d_bsum, blocks);
+                hipLaunchKernelGGL(kp_compact, dim3(blocks), dim3(256), 0, stream, pa[cur_a], pa[cur_a ^ 1], d_cnt, t, d_keep, d_bsum,
+                                   blocks);
+                hipLaunchKernelGGL(kp_count, dim3(1), dim3(1), 0, stream, d_cnt, d_bsum, d_last, blocks);
+                cur_a ^= 1;
+                uint32_t next = 0;
+                B_TRY(hipMemcpyAsync(&next, d_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                B_TRY(hipStreamSynchronize(stream));
+                if (next >= count || ++passes > 4096) {  // (cannot happen: the closest pair is always mutual)
+                    stuck = true;
+                    break;
+                }
+                count = next;
+            }
+            if (!stuck) {
+                hipLaunchKernelGGL(kb_reset_emit, dim3(1), dim3(1), 0, stream, g);
+                hipLaunchKernelGGL(kp_finish, dim3(1), dim3(1), 0, stream, pa[cur_a], t, queue[0], d_root);
+                for (int pass = 0; pass < ploc_rot; pass++) {  // the refit's tree rotations on top (boxes recomputed: same values)
+                    B_TRY(hipMemsetAsync(t.flag, 0, ni * sizeof(uint32_t), stream));
+                    hipLaunchKernelGGL(kb_refit, dim3(nb), dim3(256), 0, stream, d_prims, order, (int)n, t, 1);
+                }
+                int q = 0;
+                uint32_t cnt = 1;
+                levels = 0;
+                bool too_deep = false;
+                while (cnt > 0) {
+                    if (levels >= (uint32_t)kMaxBvhDepth) {
+                        too_deep = true;
+                        break;
+                    }
+                    hipLaunchKernelGGL(kb_emit, dim3((cnt + 255u) / 256u), dim3(256), 0, stream, d_prims, order, t, queue[q],
+                                       queue[q ^ 1], g, q, pool, max_nodes);
+                    hipLaunchKernelGGL(kb_next_level, dim3(1), dim3(1), 0, stream, g, q);
+                    B_TRY(hipMemcpyAsync(&hg, g, sizeof(hg), hipMemcpyDeviceToHost, stream));
+                    B_TRY(hipStreamSynchronize(stream));
+                    cnt = hg.q_count[q ^ 1];
+                    q ^= 1;
+                    levels++;
+                }
+                if (!too_deep) {
+                    ploc_done = true;
+                    r.ploc_passes = (uint32_t)passes;
+                    r.rotation_passes = (uint32_t)ploc_rot;
+                }
+            }
+        }
+        for (int rot_passes = rot_default; !ploc_done; rot_passes = 0) {
             B_TRY(hipMemsetAsync(t.flag, 0, ni * sizeof(uint32_t), stream));
             B_TRY(hipMemsetAsync(queue[0], 0, sizeof(ull), stream));  // first item: binary root 0 -> node 0
             hipLaunchKernelGGL(kb_reset_emit, dim3(1), dim3(1), 0, stream, g);

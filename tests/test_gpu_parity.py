@@ -589,6 +589,32 @@ def test_teapot_hdr_matches_oracle(gpu_ctx):
     gs.close()
 
 
+def test_device_builder_variants_do_not_change_results(gpu_ctx, monkeypatch):
+    """Row f3: every topology the device builder can produce -- PLOC (RT_DEVICE_BUILDER=ploc), the Morton-order tree
+    plain / with rotations / with the host-built SAH top at two cluster sizes -- gives the host tree's hits bit for bit
+    (the tree only culls) on a mesh scene with spheres, rects and a 2e4-wide floor mixed in."""
+    sc = rr.two_dragons(1.0, mesh_faces=30000, variant=0)
+    osc = O.OracleScene(sc)
+    rng = np.random.default_rng(5)
+    o, d = random_rays(rng, 60000, -8.0, 10.0)
+    to, po = osc.intersect_batch(o, d, F.RT_SMALL)
+    cfg = rr.make_cfg(48, 32, 4, seed=8)
+    ro, no, _ = osc.render(sc.camera, cfg)
+    for env in ({"RT_DEVICE_BUILDER": "ploc"}, {"RT_DEVICE_BUILDER": "ploc", "RT_PLOC_RADIUS": "4", "RT_PLOC_ROTATE_PASSES": "0"},
+                {"RT_LBVH_ROTATE_PASSES": "0"}, {"RT_LBVH_ROTATE_PASSES": "3", "RT_LBVH_SAH_CLUSTER": "0"},
+                {"RT_LBVH_SAH_CLUSTER": "32"}, {"RT_LBVH_SAH_CLUSTER": "1024"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        gs = gpu_ctx.upload(sc, device_build=True)
+        tg, pg = gpu_ctx.intersect_batch(gs, o, d, F.RT_SMALL)
+        assert np.array_equal(pg, po) and np.array_equal(tg, to), env
+        rg, ng, _ = gpu_ctx.render(gs, sc.camera, cfg)
+        assert np.array_equal(rg, ro) and np.array_equal(ng, no), env
+        gs.close()
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 def test_rough_glass_in_the_cornell_box(gpu_ctx):
     """Rough dielectric under an AREA light: the kernels compiled with the f4 features also carry the old paths."""
     from tests import oracle_ffi

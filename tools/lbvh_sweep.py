@@ -27,7 +27,11 @@ def run(label, dev, env):
         stc.tris_tested / stc.rays, st.trace_ms), flush=True)
     gs.close()
 run("host_sah", False, {})
+for radius in (8, 16, 32):
+    for rot in (0, 1, 2):
+        run(f"ploc radius {radius} rot {rot}", True, {"RT_DEVICE_BUILDER": "ploc", "RT_PLOC_RADIUS": radius, "RT_PLOC_ROTATE_PASSES": rot})
+os.environ["RT_DEVICE_BUILDER"] = "lbvh"
 for rot in (2,):
-    for sah in (0, 4096, 256, 64, 16, 4, 2):
+    for sah in (0, 256, 64):
         run(f"lbvh rot{rot} sah_cluster {sah}", True, {"RT_LBVH_ROTATE_PASSES": rot, "RT_LBVH_SAH_CLUSTER": sah})
-run("lbvh rot0 sah_cluster 2", True, {"RT_LBVH_ROTATE_PASSES": 0, "RT_LBVH_SAH_CLUSTER": 2})
+run("lbvh plain", True, {"RT_LBVH_ROTATE_PASSES": 0, "RT_LBVH_SAH_CLUSTER": 0})
