@@ -807,8 +807,11 @@ static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cac
         leaf_tri.assign(np * 9, 0.0);
         leaf_nrm.assign(any_normals ? np * 9 : 0, 0.0);
         leaf_meta.assign(np, LeafMeta{});
+        std::atomic<uint64_t> n_tri_atomic{0};
+        const unsigned fill_threads = np >= 65536 ? std::max(1u, std::min(16u, std::thread::hardware_concurrency())) : 1u;
+        auto fill = [&](size_t i0, size_t i1) {
         uint64_t n_tri_host = 0;
-        for (size_t i = 0; i < np; i++) {
+        for (size_t i = i0; i < i1; i++) {
             const uint32_t id = bvh.order[i];
             const rt_primitive& p = s->prims[id];
             leaf_meta[i] = LeafMeta{(p.mat_index & kMetaMatMask) | (p.flip ? kMetaFlip : 0u), p.light_index};
@@ -831,10 +834,22 @@ static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cac
                 leaf_prim[i] = id | kLeafOther;
             }
         }
+        n_tri_atomic += n_tri_host;
+        };
+        {   // the leaf slots are independent: filled by slices on several threads
+            std::vector<std::thread> th;
+            for (unsigned k = 1; k < fill_threads; k++) th.emplace_back(fill, np * k / fill_threads, np * (k + 1) / fill_threads);
+            fill(0, np / fill_threads);
+            for (auto& t : th) t.join();
+        }
+        const uint64_t n_tri_host = n_tri_atomic.load();
         cache.nodes = std::move(bvh.nodes);
 #if !RT_BVH8
         top_of_tree_first(cache.nodes, 256);
 #endif
+        if (getenv("RT_DIAG"))
+            fprintf(stderr, "[rt diag] commit: tree + leaf arrays on the host %.1f ms\n",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         cache.depth = bvh.depth;
         cache.n_tri = n_tri_host;
         cache.valid = true;

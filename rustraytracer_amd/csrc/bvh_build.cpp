@@ -12,6 +12,11 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <chrono>
+#include <cstdio>
 #include <thread>
 #include <cmath>
 #include <cstdlib>
@@ -69,6 +74,58 @@ struct Deferred {
     int32_t node;  // placeholder in the parent builder's `bin`
 };
 
+// T - 1 helper threads that run one job at a time, all of them and the caller (index 0): the data-parallel loops of the
+// builder's large top nodes.  Created once per build: spawning threads per loop cost more than the loops.
+struct ForkJoin {
+    unsigned T;
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv, done_cv;
+    const std::function<void(unsigned)>* job = nullptr;
+    unsigned long long gen = 0;
+    unsigned pending = 0;
+    bool stop = false;
+    explicit ForkJoin(unsigned n) : T(n) {
+        for (unsigned k = 1; k < T; k++)
+            th.emplace_back([this, k] {
+                unsigned long long seen = 0;
+                for (;;) {
+                    const std::function<void(unsigned)>* f;
+                    {
+                        std::unique_lock<std::mutex> lk(m);
+                        cv.wait(lk, [&] { return stop || gen != seen; });
+                        if (stop) return;
+                        seen = gen;
+                        f = job;
+                    }
+                    (*f)(k);
+                    std::lock_guard<std::mutex> lk(m);
+                    if (--pending == 0) done_cv.notify_one();
+                }
+            });
+    }
+    void run(const std::function<void(unsigned)>& f) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            job = &f;
+            gen++;
+            pending = T - 1;
+        }
+        cv.notify_all();
+        f(0u);
+        std::unique_lock<std::mutex> lk(m);
+        done_cv.wait(lk, [&] { return pending == 0; });
+    }
+    ~ForkJoin() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+    }
+};
+
 struct Builder {
     const rt_primitive* prims;
     std::vector<uint32_t> order_store;  // primitive ids, partitioned in place (owned by the top builder)
@@ -79,8 +136,26 @@ struct Builder {
     // parallel build: subtrees of at least `defer_min` primitives at depth >= `defer_depth` are left as
     // placeholders for worker threads (each builds into its own `bin`; the ranges of `order` are disjoint)
     uint32_t defer_depth = 0xffffffffu;
-    size_t defer_min = 0;
+    size_t defer_min = 0, defer_max = ~(size_t)0;
     std::vector<Deferred> deferred;
+    // The nodes above the deferred subtrees are few and large (the root: every primitive): their per-primitive loops --
+    // bounds, centroid bounds, the three binning passes, the largest-primitive scan -- run on `par_threads` threads,
+    // each over a contiguous chunk with its own accumulators, merged in chunk order (min / max / + only: the same
+    // values as the serial loop, so the same tree).  1 in the worker builders.
+    unsigned par_threads = 1;
+    ForkJoin* pool = nullptr;  // the top builder's helper threads (created once per build, build_binary)
+    static constexpr size_t kParMin = 65536;
+    template <typename F>
+    void par_chunks(size_t b, size_t e, F&& fn) const {  // fn(chunk index, begin, end)
+        const size_t n = e - b;
+        const unsigned T = (pool && par_threads > 1 && n >= kParMin) ? par_threads : 1u;
+        if (T == 1) {
+            fn(0u, b, e);
+            return;
+        }
+        pool->run([&](unsigned k) { fn(k, b + n * k / T, b + n * (k + 1) / T); });
+    }
+    unsigned n_chunks(size_t b, size_t e) const { return (pool && par_threads > 1 && e - b >= kParMin) ? par_threads : 1u; }
     uint32_t sah_depth = 32;  // experiment knobs: RT_BVH_SAH_DEPTH, RT_BVH_BINS
     int n_bins = 16;
     size_t max_leaf = (size_t)kLeafTargetPrims;  // RT_BVH_LEAF
@@ -110,9 +185,15 @@ struct Builder {
     double centroid(uint32_t id, int axis) const { return axis == 0 ? cx[id] : (axis == 1 ? cy[id] : cz[id]); }
 
     Box bounds(size_t b, size_t e) const {
-        Box bx;
-        bx.reset();
-        for (size_t i = b; i < e; i++) bx.grow(prims[order[i]].bbox_min, prims[order[i]].bbox_max);
+        std::vector<Box> part(n_chunks(b, e));
+        par_chunks(b, e, [&](unsigned k, size_t cb, size_t ce) {
+            Box bx;
+            bx.reset();
+            for (size_t i = cb; i < ce; i++) bx.grow(prims[order[i]].bbox_min, prims[order[i]].bbox_max);
+            part[k] = bx;
+        });
+        Box bx = part[0];
+        for (size_t k = 1; k < part.size(); k++) bx.grow(part[k]);
         return bx;
     }
 
@@ -132,7 +213,7 @@ struct Builder {
             bin[me].leaf_ref = -1 - (int32_t)((uint32_t)(b * 8 + (n - 1)) | (any_other ? kLeafCodeOther : 0u));
             return me;
         }
-        if (depth >= defer_depth && n >= defer_min) {  // a worker thread builds this subtree
+        if (depth >= defer_depth && n >= defer_min && n <= defer_max) {  // a worker thread builds this subtree
             deferred.push_back(Deferred{b, e, depth, me});
             return me;
         }
@@ -142,12 +223,31 @@ struct Builder {
             cmn[a] = std::numeric_limits<double>::infinity();
             cmx[a] = -cmn[a];
         }
-        for (size_t i = b; i < e; i++)
-            for (int a = 0; a < 3; a++) {
-                double c = centroid(order[i], a);
-                cmn[a] = std::min(cmn[a], c);
-                cmx[a] = std::max(cmx[a], c);
-            }
+        {
+            struct CB {
+                double mn[3], mx[3];
+            };
+            std::vector<CB> part(n_chunks(b, e));
+            par_chunks(b, e, [&](unsigned k, size_t cb, size_t ce) {
+                CB c;
+                for (int a = 0; a < 3; a++) {
+                    c.mn[a] = std::numeric_limits<double>::infinity();
+                    c.mx[a] = -c.mn[a];
+                }
+                for (size_t i = cb; i < ce; i++)
+                    for (int a = 0; a < 3; a++) {
+                        const double v = centroid(order[i], a);
+                        c.mn[a] = std::min(c.mn[a], v);
+                        c.mx[a] = std::max(c.mx[a], v);
+                    }
+                part[k] = c;
+            });
+            for (const CB& c : part)
+                for (int a = 0; a < 3; a++) {
+                    cmn[a] = std::min(cmn[a], c.mn[a]);
+                    cmx[a] = std::max(cmx[a], c.mx[a]);
+                }
+        }
         size_t mid = b;
         bool split_done = false;
         if (depth < sah_depth) {  // SAH above, object median below: total binary depth <= sah_depth + ceil(log2(N/4))
@@ -165,11 +265,30 @@ struct Builder {
                     cnt[k] = 0;
                 }
                 double scale = (double)NB / ext;
-                for (size_t i = b; i < e; i++) {
-                    int k = (int)((centroid(order[i], a) - cmn[a]) * scale);
-                    k = std::min(std::max(k, 0), NB - 1);
-                    cnt[k]++;
-                    bb[k].grow(prims[order[i]].bbox_min, prims[order[i]].bbox_max);
+                {
+                    struct Bins {
+                        Box bb[NBMAX];
+                        size_t cnt[NBMAX];
+                    };
+                    std::vector<Bins> part(n_chunks(b, e));
+                    par_chunks(b, e, [&](unsigned kc, size_t cb, size_t ce) {
+                        Bins& bn = part[kc];
+                        for (int k = 0; k < NB; k++) {
+                            bn.bb[k].reset();
+                            bn.cnt[k] = 0;
+                        }
+                        for (size_t i = cb; i < ce; i++) {
+                            int k = (int)((centroid(order[i], a) - cmn[a]) * scale);
+                            k = std::min(std::max(k, 0), NB - 1);
+                            bn.cnt[k]++;
+                            bn.bb[k].grow(prims[order[i]].bbox_min, prims[order[i]].bbox_max);
+                        }
+                    });
+                    for (const Bins& bn : part)
+                        for (int k = 0; k < NB; k++) {
+                            cnt[k] += bn.cnt[k];
+                            if (bn.cnt[k]) bb[k].grow(bn.bb[k]);
+                        }
                 }
                 double right_area[NBMAX];
                 size_t right_cnt[NBMAX];
@@ -204,21 +323,46 @@ struct Builder {
             if (n > 2) {
                 size_t big = b;
                 double big_area = -1.0;
-                for (size_t i = b; i < e; i++) {
-                    Box pb;
-                    pb.reset();
-                    pb.grow(prims[order[i]].bbox_min, prims[order[i]].bbox_max);
-                    const double a = pb.half_area();
-                    if (a > big_area) {
-                        big_area = a;
-                        big = i;
-                    }
+                {
+                    struct Big {
+                        size_t i;
+                        double a;
+                    };
+                    std::vector<Big> part(n_chunks(b, e));
+                    par_chunks(b, e, [&](unsigned k, size_t cb, size_t ce) {
+                        Big g{cb, -1.0};
+                        for (size_t i = cb; i < ce; i++) {
+                            Box pb;
+                            pb.reset();
+                            pb.grow(prims[order[i]].bbox_min, prims[order[i]].bbox_max);
+                            const double a = pb.half_area();
+                            if (a > g.a) {
+                                g.a = a;
+                                g.i = i;
+                            }
+                        }
+                        part[k] = g;
+                    });
+                    for (const Big& g : part)  // chunk order: the first of equal areas wins, as in the serial scan
+                        if (g.a > big_area) {
+                            big_area = g.a;
+                            big = g.i;
+                        }
                 }
                 if (big_area * 3.0 >= bin[me].box.half_area()) {
                     Box rest;
                     rest.reset();
-                    for (size_t i = b; i < e; i++)
-                        if (i != big) rest.grow(prims[order[i]].bbox_min, prims[order[i]].bbox_max);
+                    {
+                        std::vector<Box> part(n_chunks(b, e));
+                        par_chunks(b, e, [&](unsigned k, size_t cb, size_t ce) {
+                            Box r;
+                            r.reset();
+                            for (size_t i = cb; i < ce; i++)
+                                if (i != big) r.grow(prims[order[i]].bbox_min, prims[order[i]].bbox_max);
+                            part[k] = r;
+                        });
+                        for (const Box& r : part) rest.grow(r);
+                    }
                     const double cost = big_area + rest.half_area() * (double)(n - 1);
                     if (cost < best_cost) {
                         std::swap(order[b], order[big]);
@@ -326,10 +470,26 @@ struct Collapser {
 static int32_t build_binary(Builder& bd, size_t n) {
     const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     if (hw > 1 && n >= 65536) {
-        bd.defer_depth = 5;
+        // subtrees of at most 1/64 of the scene go to the worker threads (a hundred-odd tasks, dealt dynamically: the
+        // depth-5 rule of rounds 1-2 produced 8 tasks of very different size for two_dragons); the large nodes above them
+        // are built here with their per-primitive loops spread over the threads
+        bd.defer_depth = 0;
         bd.defer_min = 2048;
+        bd.defer_max = std::max<size_t>(4096, n / 64);
+        bd.par_threads = hw;
     }
-    const int32_t root = bd.build(0, n, 0);
+    const auto t0 = std::chrono::steady_clock::now();
+    int32_t root;
+    {
+        ForkJoin pool(bd.par_threads);
+        if (bd.par_threads > 1) bd.pool = &pool;
+        root = bd.build(0, n, 0);
+        bd.pool = nullptr;
+    }
+    if (getenv("RT_DIAG"))
+        fprintf(stderr, "[rt diag] host BVH: large top nodes %.1f ms (%zu subtrees left to the workers)\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), bd.deferred.size());
+    const auto t1 = std::chrono::steady_clock::now();
     if (!bd.deferred.empty()) {
         // workers: one private Builder per deferred subtree, same splits as the serial build would make
         std::vector<Builder> subs;
@@ -366,6 +526,9 @@ static int32_t build_binary(Builder& bd, size_t n) {
             }
         }
     }
+    if (getenv("RT_DIAG"))
+        fprintf(stderr, "[rt diag] host BVH: worker subtrees + splice %.1f ms\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
     return root;
 }
 

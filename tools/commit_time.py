@@ -1,9 +1,22 @@
-import sys, os, time
+"""Host commit time of the bench scenes (rt_scene_commit: BVH build + leaf layout + uploads), three commits each.
+usage: python tools/commit_time.py   (on the GPU box)"""
+import os
+import sys
+import time
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rustraytracer_amd as rr
+
 ctx = rr.Context(0)
-for preset, faces in (("cornell_box_statue", 400000), ("plastic_dragon", 871414), ("two_dragons", 871414)):
-    t = time.time(); sc = rr.Scene(preset, 1.0, faces, None, 0); t1 = time.time() - t
-    t = time.time(); gs = ctx.upload(sc); t2 = time.time() - t
-    print(preset, faces, "host scene build %.2fs  rt_scene_* + commit (BVH + upload) %.2fs" % (t1, t2), gs.info())
-    gs.close()
+for name, make in (("c2", lambda: rr.cornell_box_statue(mesh_faces=400000, variant=0)),
+                   ("c3", lambda: rr.plastic_dragon(mesh_faces=871414, variant=1)),
+                   ("c4", lambda: rr.two_dragons(1920 / 1080, mesh_faces=871414, variant=0))):
+    sc = make()
+    ts = []
+    for k in range(3):
+        t0 = time.time()
+        gs = ctx.upload(sc)
+        ts.append((time.time() - t0) * 1e3)
+        info = gs.info()
+        gs.close()
+    print(name, "n_prims", info["n_prims"], "commit wall ms", " ".join("%.0f" % t for t in ts), "build_ms(last)", round(info["build_ms"]), flush=True)
