@@ -21,6 +21,7 @@ struct DeviceBvh {
     float build_ms = 0.0f;         // device time of the whole build (HIP events)
     uint32_t rotation_passes = 0;  // refit passes that applied tree rotations (0: plain Morton-order tree)
     uint32_t sah_top_clusters = 0; // leaves of the host-built SAH top (0: the top is the Morton-order tree's own)
+    uint32_t sah_bottom_clusters = 0; // clusters whose inner topology was rebuilt by binned SAH on the device
     uint32_t ploc_passes = 0;      // > 0: the topology is PLOC's (agglomeration passes it took); 0: the Morton-order tree
 };
 

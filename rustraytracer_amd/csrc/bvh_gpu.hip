@@ -476,6 +476,375 @@ __global__ __launch_bounds__(256) void kb_relink(Tree t, const int32_t* __restri
     set_parent(t, nr[i], p);
 }
 
+// ---- SAH bottom: the topology INSIDE every cluster below the cut is rebuilt by a binned-SAH top-down build (16 bins,
+// three axes, cost = area * count per side, down to one primitive per leaf -- the host builder's rule without its
+// outlier candidate).  A cluster is a subtree of the radix tree: it covers the sorted positions [lo, hi] and owns exactly
+// the internal nodes {lo .. hi-1} when its root is node lo, {lo+1 .. hi} when its root is node hi (Karras' numbering: a
+// left child is the LAST index of its range, a right child the FIRST) -- hi - lo nodes for hi - lo + 1 leaves, so the new
+// topology is written into the cluster's own nodes in preorder and the root keeps its id (and its link from above).
+// One wave per cluster, everything in LDS (binary32 copies of the leaf boxes: decisions only, the exact boxes come from
+// the refit that follows):
+//   phase 1, ranges of more than kSerialMax primitives, the wave together: centroid bounds by a butterfly; lane
+//            (axis, bin) of 48 scans the range and keeps its bin's box and count; prefix / suffix unions per lane; wave
+//            arg-min of the cost (ties: lowest axis, then lowest bin -- the serial scan's order); ballot partition;
+//   phase 2, the ranges that are left (<= kSerialMax), one lane each: the same build serially.
+// Both process the smaller half first, so the explicit stacks hold <= log2 entries.
+constexpr int kClusterBins = 16;
+constexpr int kClusterMax = 1024;  // primitives per cluster (LDS: 24 B of boxes each); larger clusters keep the radix topology
+constexpr int kSerialMax = 32;
+
+struct ClusterLds {
+    float bx[6][kClusterMax];
+    uint16_t perm[kClusterMax];  // local leaf index per position
+    uint16_t tmp[kClusterMax];
+    uint32_t task_ab[kClusterMax / 2];  // a | b << 16
+    uint16_t task_k[kClusterMax / 2];
+    float bin[3 * kClusterBins][6];
+    uint32_t bin_cnt[3 * kClusterBins];
+    uint32_t stack_ab[16];
+    uint16_t stack_k[16];
+};
+
+struct ClusterIds {
+    uint32_t lo, hi;
+    bool root_is_lo;
+    __device__ int32_t node(uint32_t k) const {  // k-th node of the cluster in preorder, 0 = its root
+        return (int32_t)(root_is_lo ? lo + k : (k == 0u ? hi : lo + k));
+    }
+};
+
+__device__ inline float half_area3(const float* b) {
+    const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+__device__ inline int cluster_bin(float c2, float cmn, float scale) {
+    const int k = (int)((c2 - cmn) * scale);
+    return k < 0 ? 0 : (k > kClusterBins - 1 ? kClusterBins - 1 : k);
+}
+// node k of the cluster splits positions [a, mid) | [mid, b)
+__device__ inline void cluster_link(const Tree& t, const ClusterLds& L, const ClusterIds& id, uint32_t a, uint32_t mid,
+                                    uint32_t b, uint32_t k) {
+    const int32_t me = id.node(k);
+    const uint32_t nl = mid - a, nr = b - mid;
+    const int32_t lc = nl == 1u ? ~(int32_t)(id.lo + L.perm[a]) : id.node(k + 1u);
+    const int32_t rc = nr == 1u ? ~(int32_t)(id.lo + L.perm[mid]) : id.node(k + nl);
+    t.left[me] = lc;
+    t.right[me] = rc;
+    set_parent(t, lc, me);
+    set_parent(t, rc, me);
+}
+
+// phase 2: one lane builds positions [a0, b0) (node k0) on its own
+__device__ void cluster_serial(const Tree& t, ClusterLds& L, const ClusterIds& id, uint32_t a0, uint32_t b0, uint32_t k0) {
+    struct Range {
+        uint32_t a, b, k;
+    };
+    Range stack[8];  // smaller half first: <= log2(kSerialMax) pending
+    int sp = 0;
+    Range rg{a0, b0, k0};
+    for (;;) {
+        const uint32_t a = rg.a, b = rg.b, n = b - a;
+        uint32_t mid = a + n / 2u;
+        if (n > 2u) {
+            float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (uint32_t i = a; i < b; i++) {
+                const uint32_t p = L.perm[i];
+                for (int x = 0; x < 3; x++) {
+                    const float c = L.bx[x][p] + L.bx[3 + x][p];
+                    cmn[x] = fminf(cmn[x], c);
+                    cmx[x] = fmaxf(cmx[x], c);
+                }
+            }
+            float best_cost = INFINITY;
+            int best_axis = -1, best_bin = -1;
+            for (int x = 0; x < 3; x++) {
+                const float ext = cmx[x] - cmn[x];
+                if (!(ext > 0.0f)) continue;
+                const float scale = (float)kClusterBins / ext;
+                float bb[kClusterBins][6];
+                uint32_t cnt[kClusterBins];
+                for (int k = 0; k < kClusterBins; k++) {
+                    for (int c = 0; c < 3; c++) {
+                        bb[k][c] = INFINITY;
+                        bb[k][3 + c] = -INFINITY;
+                    }
+                    cnt[k] = 0;
+                }
+                for (uint32_t i = a; i < b; i++) {
+                    const uint32_t p = L.perm[i];
+                    const int k = cluster_bin(L.bx[x][p] + L.bx[3 + x][p], cmn[x], scale);
+                    cnt[k]++;
+                    for (int c = 0; c < 3; c++) {
+                        bb[k][c] = fminf(bb[k][c], L.bx[c][p]);
+                        bb[k][3 + c] = fmaxf(bb[k][3 + c], L.bx[3 + c][p]);
+                    }
+                }
+                float right_cost[kClusterBins];  // area * count of bins k .. last (< 0: empty)
+                float acc[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                uint32_t c = 0;
+                for (int k = kClusterBins - 1; k > 0; k--) {
+                    if (cnt[k]) {
+                        for (int d = 0; d < 3; d++) {
+                            acc[d] = fminf(acc[d], bb[k][d]);
+                            acc[3 + d] = fmaxf(acc[3 + d], bb[k][3 + d]);
+                        }
+                        c += cnt[k];
+                    }
+                    right_cost[k] = c ? half_area3(acc) * (float)c : -1.0f;
+                }
+                for (int d = 0; d < 3; d++) {
+                    acc[d] = INFINITY;
+                    acc[3 + d] = -INFINITY;
+                }
+                c = 0;
+                for (int k = 0; k < kClusterBins - 1; k++) {
+                    if (cnt[k]) {
+                        for (int d = 0; d < 3; d++) {
+                            acc[d] = fminf(acc[d], bb[k][d]);
+                            acc[3 + d] = fmaxf(acc[3 + d], bb[k][3 + d]);
+                        }
+                        c += cnt[k];
+                    }
+                    if (c == 0u || right_cost[k + 1] < 0.0f) continue;
+                    const float cost = half_area3(acc) * (float)c + right_cost[k + 1];
+                    if (cost < best_cost) {
+                        best_cost = cost;
+                        best_axis = x;
+                        best_bin = k;
+                    }
+                }
+            }
+            if (best_axis >= 0) {
+                const float scale = (float)kClusterBins / (cmx[best_axis] - cmn[best_axis]);
+                uint32_t i = a, j = b;  // in-place partition: bins <= best_bin first
+                while (i < j) {
+                    const uint16_t pi = L.perm[i];
+                    if (cluster_bin(L.bx[best_axis][pi] + L.bx[3 + best_axis][pi], cmn[best_axis], scale) <= best_bin) {
+                        i++;
+                    } else {
+                        j--;
+                        L.perm[i] = L.perm[j];
+                        L.perm[j] = pi;
+                    }
+                }
+                if (i > a && i < b) mid = i;  // (always: both sides of a candidate hold primitives)
+            }
+        }
+        cluster_link(t, L, id, a, mid, b, rg.k);
+        const uint32_t nl = mid - a, nr = b - mid;
+        const Range rl{a, mid, rg.k + 1u}, rr{mid, b, rg.k + nl};
+        const bool l_in = nl >= 2u, r_in = nr >= 2u;
+        if (l_in && r_in) {
+            if (nl <= nr) {
+                stack[sp++] = rr;
+                rg = rl;
+            } else {
+                stack[sp++] = rl;
+                rg = rr;
+            }
+        } else if (l_in) {
+            rg = rl;
+        } else if (r_in) {
+            rg = rr;
+        } else if (sp > 0) {
+            rg = stack[--sp];
+        } else {
+            break;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void kb_cluster_sah(const rt_primitive* __restrict__ prims,
+                                                     const uint32_t* __restrict__ order, Tree t,
+                                                     const int32_t* __restrict__ refs, uint32_t n_cut, uint32_t* rebuilt) {
+    __shared__ ClusterLds L;
+    const int32_t root = refs[blockIdx.x];
+    if (root < 0) return;  // a stray single primitive
+    ClusterIds id;
+    id.lo = t.first[root];
+    id.hi = t.last[root];
+    id.root_is_lo = (uint32_t)root == id.lo;
+    const uint32_t m = id.hi - id.lo + 1u;
+    if (m < 3u || m > (uint32_t)kClusterMax) return;  // two leaves have one topology
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t i = lane; i < m; i += 64u) {
+        const rt_primitive& p = prims[order[id.lo + i]];
+        for (int x = 0; x < 3; x++) {
+            L.bx[x][i] = (float)p.bbox_min[x];
+            L.bx[3 + x][i] = (float)p.bbox_max[x];
+        }
+        L.perm[i] = (uint16_t)i;
+    }
+    uint32_t n_tasks = 0;
+    int sp = 0;
+    if (m <= (uint32_t)kSerialMax) {
+        L.task_ab[0] = m << 16;
+        L.task_k[0] = 0;
+        n_tasks = 1;
+    } else {
+        L.stack_ab[0] = m << 16;
+        L.stack_k[0] = 0;
+        sp = 1;
+    }
+    __syncthreads();
+    // ---- phase 1 (every value that steers the control flow is wave-uniform)
+    const int ax = lane < 48u ? (int)(lane >> 4) : 2, kbin = (int)(lane & 15u);
+    while (sp > 0) {
+        --sp;
+        uint32_t a = L.stack_ab[sp] & 0xffffu, b = L.stack_ab[sp] >> 16, k = L.stack_k[sp];
+        for (;;) {  // [a, b) has more than kSerialMax primitives
+            const uint32_t n = b - a;
+            float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (uint32_t i = a + lane; i < b; i += 64u) {
+                const uint32_t p = L.perm[i];
+                for (int x = 0; x < 3; x++) {
+                    const float c = L.bx[x][p] + L.bx[3 + x][p];
+                    cmn[x] = fminf(cmn[x], c);
+                    cmx[x] = fmaxf(cmx[x], c);
+                }
+            }
+            for (int off = 32; off >= 1; off >>= 1)
+                for (int x = 0; x < 3; x++) {
+                    cmn[x] = fminf(cmn[x], __shfl_xor(cmn[x], off));
+                    cmx[x] = fmaxf(cmx[x], __shfl_xor(cmx[x], off));
+                }
+            const float my_mn = ax == 0 ? cmn[0] : (ax == 1 ? cmn[1] : cmn[2]);
+            const float my_ext = (ax == 0 ? cmx[0] : (ax == 1 ? cmx[1] : cmx[2])) - my_mn;
+            const bool axis_ok = my_ext > 0.0f;
+            const float my_scale = axis_ok ? (float)kClusterBins / my_ext : 0.0f;
+            float bb[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            uint32_t cnt = 0;
+            for (uint32_t i = a; i < b; i++) {
+                const uint32_t p = L.perm[i];
+                if (cluster_bin(L.bx[ax][p] + L.bx[3 + ax][p], my_mn, my_scale) == kbin) {
+                    cnt++;
+                    for (int c = 0; c < 3; c++) {
+                        bb[c] = fminf(bb[c], L.bx[c][p]);
+                        bb[3 + c] = fmaxf(bb[3 + c], L.bx[3 + c][p]);
+                    }
+                }
+            }
+            if (lane < 48u) {
+                for (int c = 0; c < 6; c++) L.bin[lane][c] = bb[c];
+                L.bin_cnt[lane] = cnt;
+            }
+            __syncthreads();
+            float cost = INFINITY;
+            if (lane < 48u && axis_ok && kbin < kClusterBins - 1) {
+                float lb[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                float rb[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                uint32_t cl = 0, cr = 0;
+                for (int j = 0; j < kClusterBins; j++) {
+                    const int q = ax * kClusterBins + j;
+                    const uint32_t cj = L.bin_cnt[q];
+                    if (!cj) continue;
+                    if (j <= kbin) {
+                        cl += cj;
+                        for (int c = 0; c < 3; c++) {
+                            lb[c] = fminf(lb[c], L.bin[q][c]);
+                            lb[3 + c] = fmaxf(lb[3 + c], L.bin[q][3 + c]);
+                        }
+                    } else {
+                        cr += cj;
+                        for (int c = 0; c < 3; c++) {
+                            rb[c] = fminf(rb[c], L.bin[q][c]);
+                            rb[3 + c] = fmaxf(rb[3 + c], L.bin[q][3 + c]);
+                        }
+                    }
+                }
+                if (cl && cr) cost = half_area3(lb) * (float)cl + half_area3(rb) * (float)cr;
+            }
+            uint32_t who = lane;
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float oc = __shfl_xor(cost, off);
+                const uint32_t ow = __shfl_xor(who, off);
+                if (oc < cost || (oc == cost && ow < who)) {
+                    cost = oc;
+                    who = ow;
+                }
+            }
+            uint32_t mid = a + n / 2u;
+            if (cost < INFINITY) {
+                const int best_axis = (int)(who >> 4), best_bin = (int)(who & 15u);
+                const float bmn = best_axis == 0 ? cmn[0] : (best_axis == 1 ? cmn[1] : cmn[2]);
+                const float bscale = (float)kClusterBins / ((best_axis == 0 ? cmx[0] : (best_axis == 1 ? cmx[1] : cmx[2])) - bmn);
+                uint32_t total_left = 0;
+                for (uint32_t base = a; base < b; base += 64u) {
+                    const uint32_t i = base + lane;
+                    const uint32_t p = i < b ? L.perm[i] : 0u;
+                    const bool goes_left = i < b && cluster_bin(L.bx[best_axis][p] + L.bx[3 + best_axis][p], bmn, bscale) <= best_bin;
+                    total_left += (uint32_t)__popcll(__ballot(goes_left));
+                }
+                if (total_left > 0u && total_left < n) {
+                    uint32_t lcur = a, rcur = a + total_left;
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    for (uint32_t base = a; base < b; base += 64u) {
+                        const uint32_t i = base + lane;
+                        const bool in = i < b;
+                        const uint32_t p = in ? L.perm[i] : 0u;
+                        const bool goes_left = in && cluster_bin(L.bx[best_axis][p] + L.bx[3 + best_axis][p], bmn, bscale) <= best_bin;
+                        const unsigned long long bl = __ballot(goes_left), br = __ballot(in && !goes_left);
+                        if (goes_left)
+                            L.tmp[lcur + (uint32_t)__popcll(bl & below)] = (uint16_t)p;
+                        else if (in)
+                            L.tmp[rcur + (uint32_t)__popcll(br & below)] = (uint16_t)p;
+                        lcur += (uint32_t)__popcll(bl);
+                        rcur += (uint32_t)__popcll(br);
+                    }
+                    __syncthreads();
+                    for (uint32_t i = a + lane; i < b; i += 64u) L.perm[i] = L.tmp[i];
+                    mid = a + total_left;
+                }
+            }
+            __syncthreads();
+            if (lane == 0u) cluster_link(t, L, id, a, mid, b, k);
+            // children: a single primitive is linked already; small ranges become lane tasks; the larger of two big ones waits
+            const uint32_t nl = mid - a, nr = b - mid;
+            const uint32_t kl = k + 1u, kr = k + nl;
+            const bool l_big = nl > (uint32_t)kSerialMax, r_big = nr > (uint32_t)kSerialMax;
+            if (!l_big && nl >= 2u) {
+                L.task_ab[n_tasks] = a | (mid << 16);
+                L.task_k[n_tasks] = (uint16_t)kl;
+                n_tasks++;
+            }
+            if (!r_big && nr >= 2u) {
+                L.task_ab[n_tasks] = mid | (b << 16);
+                L.task_k[n_tasks] = (uint16_t)kr;
+                n_tasks++;
+            }
+            if (l_big && r_big) {
+                if (nl <= nr) {
+                    L.stack_ab[sp] = mid | (b << 16);
+                    L.stack_k[sp] = (uint16_t)kr;
+                    sp++;
+                    b = mid;
+                    k = kl;
+                } else {
+                    L.stack_ab[sp] = a | (mid << 16);
+                    L.stack_k[sp] = (uint16_t)kl;
+                    sp++;
+                    a = mid;
+                    k = kr;
+                }
+            } else if (l_big) {
+                b = mid;
+                k = kl;
+            } else if (r_big) {
+                a = mid;
+                k = kr;
+            } else {
+                break;
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    // ---- phase 2
+    for (uint32_t task = lane; task < n_tasks; task += 64u)
+        cluster_serial(t, L, id, L.task_ab[task] & 0xffffu, L.task_ab[task] >> 16, L.task_k[task]);
+    if (lane == 0u) atomicAdd(rebuilt, 1u);
+}
+
 // ---- PLOC: parallel locally-ordered clustering (Meister & Bittner 2018), the device builder's optional fast topology.
 // Bottom-up agglomeration along the Morton order: every cluster looks for the neighbour within +-radius positions whose
 // union with it has the smallest surface area; mutual nearest neighbours merge into a new node; the array is compacted;
@@ -869,15 +1238,20 @@ int build_bvh_device(hipStream_t stream, const rt_primitive* d_prims, const DevM
         B_TRY(tmp.get(&t.all_tri, ni));
         B_TRY(tmp.get(&queue[0], ni));
         B_TRY(tmp.get(&queue[1], ni));
-        // Tree, refit with fused rotations (RT_LBVH_ROTATE_PASSES passes, default 2; 0 = the plain Morton-order tree), 4-wide
-        // emission.  Rotations can deepen the tree: if the result does not fit the traversal stack, the tree is rebuilt
-        // without them before giving up.
-        const int rot_default = getenv("RT_LBVH_ROTATE_PASSES") ? atoi(getenv("RT_LBVH_ROTATE_PASSES")) : 2;
-        // clusters of at most this many primitives are the leaves of the host-built SAH top (0 = no SAH top)
-        const uint32_t sah_limit = getenv("RT_LBVH_SAH_CLUSTER") ? (uint32_t)atoi(getenv("RT_LBVH_SAH_CLUSTER")) : 256u;
+        // Topology: the Morton-order radix tree, cut into clusters of <= RT_LBVH_SAH_CLUSTER primitives (default 1024; 0 = no
+        // cut); above the cut a binned-SAH tree built on the host over the clusters' boxes (kb_cut / kb_relink), inside
+        // every cluster a binned-SAH tree built by one wave (kb_cluster_sah; RT_LBVH_SAH_BOTTOM=0 keeps the Morton order
+        // there).  RT_LBVH_ROTATE_PASSES refit passes apply tree rotations on top: default 0 with the SAH bottom (they
+        // cost a cornell box 20 % more node fetches there and buy the dragons 0.3 %), 2 without it.  A tree too deep for the
+        // traversal stack is rebuilt plain (no rotations, no SAH) before giving up.
+        const uint32_t sah_limit = getenv("RT_LBVH_SAH_CLUSTER") ? (uint32_t)atoi(getenv("RT_LBVH_SAH_CLUSTER")) : 1024u;
+        const bool cluster_sah = getenv("RT_LBVH_SAH_BOTTOM") ? atoi(getenv("RT_LBVH_SAH_BOTTOM")) != 0 : true;
+        const bool sah_applies = kLeafTargetPrims == 1 && sah_limit > 0 && n > 4u * sah_limit;
+        const int rot_default = getenv("RT_LBVH_ROTATE_PASSES") ? atoi(getenv("RT_LBVH_ROTATE_PASSES")) : (sah_applies && cluster_sah ? 0 : 2);
         // ---- RT_DEVICE_BUILDER=ploc: the PLOC topology instead of the Morton-order tree (the fastest build -- C4 10.6 ms
-        // against 18.8 -- at the plain Morton tree's quality: 1.18-1.20 x the host tree's node fetches, where rotations + SAH
-        // top reach 1.04-1.13 in 16-70 ms; profiles/r03_lbvh_ploc_sweep.txt).  Falls back to the default when too deep.
+        // against 18.8 -- at the plain Morton tree's quality: 1.18-1.20 x the host tree's node fetches, where the default
+        // reaches 0.92-1.04 in 10-39 ms; profiles/r03_lbvh_ploc_sweep.txt, r03_lbvh_sah_bottom.txt).  Falls back to the
+        // default when too deep.
         const char* which = getenv("RT_DEVICE_BUILDER");
         bool ploc_done = false;
         if (kLeafTargetPrims == 1 && which && std::strcmp(which, "ploc") == 0) {
@@ -955,13 +1329,15 @@ int build_bvh_device(hipStream_t stream, const rt_primitive* d_prims, const DevM
                 }
             }
         }
-        for (int rot_passes = rot_default; !ploc_done; rot_passes = 0) {
+        bool plain_retry = false;  // second attempt: neither rotations nor SAH
+        for (int rot_passes = rot_default; !ploc_done; rot_passes = 0, plain_retry = true) {
             B_TRY(hipMemsetAsync(t.flag, 0, ni * sizeof(uint32_t), stream));
             B_TRY(hipMemsetAsync(queue[0], 0, sizeof(ull), stream));  // first item: binary root 0 -> node 0
             hipLaunchKernelGGL(kb_reset_emit, dim3(1), dim3(1), 0, stream, g);
             hipLaunchKernelGGL(kb_tree, dim3(nb), dim3(256), 0, stream, skeys, (int)n, t);
             bool sah_top_done = false;
-            if (rot_passes > 0 && kLeafTargetPrims == 1 && sah_limit > 0 && n > 4u * sah_limit) {
+            r.sah_top_clusters = r.sah_bottom_clusters = 0;
+            if (!plain_retry && sah_applies) {
                 // plain refit first (the cut needs the clusters' boxes), then the SAH top, then the rotation passes
                 hipLaunchKernelGGL(kb_refit, dim3(nb), dim3(256), 0, stream, d_prims, order, (int)n, t, 0);
                 const uint32_t cap = 1u << 16;
@@ -980,6 +1356,14 @@ int build_bvh_device(hipStream_t stream, const rt_primitive* d_prims, const DevM
                 B_TRY(hipStreamSynchronize(stream));
                 const uint32_t n_cut = counts[0], n_top = counts[1];
                 if (n_top >= 1 && n_top <= cap && n_cut == n_top + 1) {
+                    if (cluster_sah) {  // SAH bottom: every cluster's own nodes re-linked (device), overlaps the host's SAH top
+                        uint32_t* d_rebuilt = nullptr;
+                        B_TRY(tmp.get(&d_rebuilt, 1));
+                        B_TRY(hipMemsetAsync(d_rebuilt, 0, sizeof(uint32_t), stream));
+                        hipLaunchKernelGGL(kb_cluster_sah, dim3(n_cut), dim3(64), 0, stream, d_prims, order, t, d_refs, n_cut,
+                                           d_rebuilt);
+                        B_TRY(hipMemcpyAsync(&r.sah_bottom_clusters, d_rebuilt, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                    }
                     std::vector<int32_t> refs(n_cut), top(n_top), sl, sr;
                     std::vector<double> boxes((size_t)n_cut * 6);
                     B_TRY(hipMemcpyAsync(refs.data(), d_refs, n_cut * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
@@ -1041,7 +1425,7 @@ int build_bvh_device(hipStream_t stream, const rt_primitive* d_prims, const DevM
                 r.rotation_passes = (uint32_t)rot_passes;
                 break;
             }
-            if (rot_passes == 0)
+            if (plain_retry || (rot_passes == 0 && r.sah_top_clusters == 0))
                 return bfail(err, err_len, RT_ERR_UNSUPPORTED,
                              "device-built BVH is deeper than the traversal stack allows (%d levels): commit with the host builder",
                              kMaxBvhDepth);

@@ -591,7 +591,8 @@ def test_teapot_hdr_matches_oracle(gpu_ctx):
 
 def test_device_builder_variants_do_not_change_results(gpu_ctx, monkeypatch):
     """Row f3: every topology the device builder can produce -- PLOC (RT_DEVICE_BUILDER=ploc), the Morton-order tree
-    plain / with rotations / with the host-built SAH top at two cluster sizes -- gives the host tree's hits bit for bit
+    plain / with rotations / with the host-built SAH top at several cluster sizes, with and without the device-built SAH
+    bottom inside the clusters -- gives the host tree's hits bit for bit
     (the tree only culls) on a mesh scene with spheres, rects and a 2e4-wide floor mixed in."""
     sc = rr.two_dragons(1.0, mesh_faces=30000, variant=0)
     osc = O.OracleScene(sc)
@@ -601,8 +602,9 @@ def test_device_builder_variants_do_not_change_results(gpu_ctx, monkeypatch):
     cfg = rr.make_cfg(48, 32, 4, seed=8)
     ro, no, _ = osc.render(sc.camera, cfg)
     for env in ({"RT_DEVICE_BUILDER": "ploc"}, {"RT_DEVICE_BUILDER": "ploc", "RT_PLOC_RADIUS": "4", "RT_PLOC_ROTATE_PASSES": "0"},
-                {"RT_LBVH_ROTATE_PASSES": "0"}, {"RT_LBVH_ROTATE_PASSES": "3", "RT_LBVH_SAH_CLUSTER": "0"},
-                {"RT_LBVH_SAH_CLUSTER": "32"}, {"RT_LBVH_SAH_CLUSTER": "1024"}):
+                {"RT_LBVH_ROTATE_PASSES": "0", "RT_LBVH_SAH_CLUSTER": "0"}, {"RT_LBVH_ROTATE_PASSES": "0"},
+                {"RT_LBVH_ROTATE_PASSES": "3", "RT_LBVH_SAH_CLUSTER": "0"}, {"RT_LBVH_SAH_CLUSTER": "32"},
+                {"RT_LBVH_SAH_CLUSTER": "1024"}, {"RT_LBVH_SAH_BOTTOM": "0"}, {"RT_LBVH_SAH_CLUSTER": "4096", "RT_LBVH_ROTATE_PASSES": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         gs = gpu_ctx.upload(sc, device_build=True)

@@ -15,14 +15,21 @@ out = []
 for name, make, W, H, spp in CASES:
     sc = make()
     row = {"scene": name}
-    # device builder: plain Morton-order tree, and with 1 / 2 / 3 refit passes that apply tree rotations (bvh_gpu.hip)
-    # also: the SAH top over clusters of <= N primitives (RT_LBVH_SAH_CLUSTER, 0 = none; default 256)
-    for label, dev, rot, sah in (("host_sah", False, None, None), ("device_lbvh_plain", True, 0, 0), ("device_lbvh_rot2", True, 2, 0),
-                                 ("device_lbvh_rot2_sah1024", True, 2, 1024), ("device_lbvh", True, 2, 256),
-                                 ("device_lbvh_rot2_sah64", True, 2, 64), ("device_lbvh_rot3_sah64", True, 3, 64)):
-        if rot is not None:
-            os.environ["RT_LBVH_ROTATE_PASSES"] = str(rot)
-            os.environ["RT_LBVH_SAH_CLUSTER"] = str(sah)
+    # device builder (bvh_gpu.hip): the plain Morton-order tree; + 2 refit passes with tree rotations; + the host-built SAH top
+    # over clusters of <= 256 primitives (the default until the SAH bottom existed); the default: clusters of <= 1024,
+    # SAH top and SAH bottom, no rotations; the same with one rotation pass / with clusters of 256
+    KNOBS = ("RT_LBVH_ROTATE_PASSES", "RT_LBVH_SAH_CLUSTER", "RT_LBVH_SAH_BOTTOM")
+    for label, dev, env in (("host_sah", False, {}),
+                            ("device_lbvh_plain", True, {"RT_LBVH_ROTATE_PASSES": 0, "RT_LBVH_SAH_CLUSTER": 0}),
+                            ("device_lbvh_rot2", True, {"RT_LBVH_ROTATE_PASSES": 2, "RT_LBVH_SAH_CLUSTER": 0}),
+                            ("device_lbvh_rot2_sahtop256", True, {"RT_LBVH_ROTATE_PASSES": 2, "RT_LBVH_SAH_CLUSTER": 256, "RT_LBVH_SAH_BOTTOM": 0}),
+                            ("device_lbvh", True, {}),
+                            ("device_lbvh_rot1", True, {"RT_LBVH_ROTATE_PASSES": 1}),
+                            ("device_lbvh_cluster256", True, {"RT_LBVH_SAH_CLUSTER": 256})):
+        for k in KNOBS:
+            os.environ.pop(k, None)
+        for k, v in env.items():
+            os.environ[k] = str(v)
         t0 = time.time()
         gs = ctx.upload(sc, device_build=dev)
         wall = (time.time() - t0) * 1e3

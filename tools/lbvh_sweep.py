@@ -1,5 +1,5 @@
 """Row f3 quality sweep of the device builder's knobs on one scene (run on the GPU box).
-usage: python tools/lbvh_sweep.py [c2|c3|c4]"""
+usage: python tools/lbvh_sweep.py [c2|c3|c4] [bottom|ploc]"""
 import os
 import sys
 import time
@@ -26,12 +26,21 @@ def run(label, dev, env):
         which, label, inf["build_device_ms"], inf["n_bvh_nodes"], inf["bvh_depth"], stc.nodes_fetched / stc.rays,
         stc.tris_tested / stc.rays, st.trace_ms), flush=True)
     gs.close()
+mode = sys.argv[2] if len(sys.argv) > 2 else "bottom"
 run("host_sah", False, {})
-for radius in (8, 16, 32):
-    for rot in (0, 1, 2):
-        run(f"ploc radius {radius} rot {rot}", True, {"RT_DEVICE_BUILDER": "ploc", "RT_PLOC_RADIUS": radius, "RT_PLOC_ROTATE_PASSES": rot})
-os.environ["RT_DEVICE_BUILDER"] = "lbvh"
-for rot in (2,):
-    for sah in (0, 256, 64):
-        run(f"lbvh rot{rot} sah_cluster {sah}", True, {"RT_LBVH_ROTATE_PASSES": rot, "RT_LBVH_SAH_CLUSTER": sah})
-run("lbvh plain", True, {"RT_LBVH_ROTATE_PASSES": 0, "RT_LBVH_SAH_CLUSTER": 0})
+if mode == "ploc":
+    for radius in (8, 16, 32):
+        for rot in (0, 1, 2):
+            run(f"ploc radius {radius} rot {rot}", True, {"RT_DEVICE_BUILDER": "ploc", "RT_PLOC_RADIUS": radius, "RT_PLOC_ROTATE_PASSES": rot})
+    os.environ["RT_DEVICE_BUILDER"] = "lbvh"
+    for rot in (2,):
+        for sah in (0, 256, 64):
+            run(f"lbvh rot{rot} sah_cluster {sah}", True, {"RT_LBVH_ROTATE_PASSES": rot, "RT_LBVH_SAH_CLUSTER": sah, "RT_LBVH_SAH_BOTTOM": 0})
+    run("lbvh plain", True, {"RT_LBVH_ROTATE_PASSES": 0, "RT_LBVH_SAH_CLUSTER": 0})
+else:  # the SAH bottom (kb_cluster_sah) against the Morton-order bottom, by cluster size and rotation passes
+    os.environ["RT_DEVICE_BUILDER"] = "lbvh"
+    run("lbvh cluster 256 morton bottom rot 2", True, {"RT_LBVH_ROTATE_PASSES": 2, "RT_LBVH_SAH_CLUSTER": 256, "RT_LBVH_SAH_BOTTOM": 0})
+    for sah in (128, 256, 512, 1024):
+        for rot in (0, 1, 2):
+            run(f"lbvh cluster {sah} sah bottom rot {rot}", True,
+                {"RT_LBVH_ROTATE_PASSES": rot, "RT_LBVH_SAH_CLUSTER": sah, "RT_LBVH_SAH_BOTTOM": 1})
