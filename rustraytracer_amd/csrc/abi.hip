@@ -1128,7 +1128,7 @@ static int run_lane(RenderJob& job, int lane_id) {
         if (!exhausted_known)
             hipLaunchKernelGGL(generate_kernel(job.f32_gen), dim3(gen_blocks), dim3(256), 0, stream, ln.st[it & 1], job.cam, job.batch,
                                c->pix_list, ln.queue[it & 1], ln.ctl);
-        const uint32_t shade_blocks = std::max(1u, (bound_active + 255) / 256);
+        const uint32_t shade_blocks = std::max(1u, (bound_active + RT_SHADE_BLOCK - 1) / RT_SHADE_BLOCK);
         const uint32_t tblocks = std::max(
             1u, (uint32_t)std::min<uint64_t>((3ull * bound_active + 255) / 256, (uint64_t)job.trace_blocks));
         hipEvent_t a = nullptr, b = nullptr;
@@ -1150,7 +1150,7 @@ static int run_lane(RenderJob& job, int lane_id) {
             ln.trace_ev.emplace_back(a, b);
         }
         ln.trace_launches++;
-        hipLaunchKernelGGL(shade_kernel(job.s->shade_variant, job.f32_shade), dim3(shade_blocks), dim3(256), 0, stream, job.s->dev, ln.st[it & 1],
+        hipLaunchKernelGGL(shade_kernel(job.s->shade_variant, job.f32_shade), dim3(shade_blocks), dim3(RT_SHADE_BLOCK), 0, stream, job.s->dev, ln.st[it & 1],
                            ln.st[(it + 1) & 1], ln.ctl, (uint32_t)it, cfg->max_depth, ln.queue[(it + 1) & 1], c->lf[0],
                            c->lf[1], c->lf[2], c->stats);
         if (!no_ev) {  // the shading kernel runs from event b (end of k_trace) to this one

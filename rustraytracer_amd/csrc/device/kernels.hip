@@ -26,6 +26,12 @@
 // independent of how tiles are split over GPUs.
 #include "shading.h"
 
+#ifndef RT_SHADE_BLOCK
+#define RT_SHADE_BLOCK 256  // threads per k_shade block = the paths dealt among its waves by class.  Measured (profiles/r03_exp_shade_block.txt,
+                            // C4 / C3 k_shade ms): 64: 923 / 123, 128: 644 / 95.4, 192: 613 / 93.6, 256: 616 / 95.0 -- and a dealing window of 2-8
+                            // blocks (tools/experiments/r03_deal_window.patch): 787-1026 / 114-146, the gathered state loads cost more than the
+                            // purer waves save
+#endif
 #ifndef RT_SHADE_LAST_WAVE
 #define RT_SHADE_LAST_WAVE 1  // k_shade (dealing instances): no barrier before the queue reservation, the block's last wave writes it
 #endif
@@ -755,6 +761,9 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
 #ifndef RT_SORT_CLASSES
 #define RT_SORT_CLASSES 5
 #endif
+#ifndef RT_SORT_FEAT0
+#define RT_SORT_FEAT0 0  // (experiment) the Lambert-only instance deals its paths too
+#endif
 #undef RT_SHADE_BOUND
 #define RT_SHADE_BOUND_RULE(F) ((F) <= RT_SHADE4_MAXFEAT ? 4 : (feat_three_waves(F) && RT_SHADE3_MAXFEAT >= 3 ? 3 : RT_SHADE_WAVES))
 #ifdef RT_F32
@@ -767,7 +776,7 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
 #define RT_SHADE_BOUND(F) RT_SHADE_BOUND_RULE(F)
 #endif
 template <int FEAT>
-__global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc, PathState in, PathState out, Ctl* ctl, uint32_t it_abs,
+__global__ __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc, PathState in, PathState out, Ctl* ctl, uint32_t it_abs,
                                                uint32_t max_depth, uint32_t* queue_out, f64_t* lfx, f64_t* lfy,
                                                f64_t* lfz, DevStats* stats) {
     const uint32_t it = it_abs % kRing, itn = (it_abs + 1) % kRing;
@@ -777,7 +786,8 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc
     // (Giving every XCD one contiguous eighth of the path list here, as k_trace does with the ray queue, was measured
     // and is 11-21 % slower for this kernel: C4 717 -> 871 ms, C3 109 -> 122.)
     const uint32_t bid = blockIdx.x;
-    __shared__ uint32_t s_cnt[4][4];  // [wave][0 = output slots, 1..3 = ext / shadow / probe rays]
+    constexpr uint32_t kSW = RT_SHADE_BLOCK / 64;  // waves per block
+    __shared__ uint32_t s_cnt[kSW][4];  // [wave][0 = output slots, 1..3 = ext / shadow / probe rays]
     __shared__ uint32_t s_base[2];    // block's base in the next path list / ray queue
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     // Deal the block's 256 paths to its lanes by what their vertex needs (mesh hit / sphere-rect hit / escaped /
@@ -785,14 +795,11 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc
     // at 24-35 active lanes of 64 (PMC).  Paths are independent and the film staging is indexed by
     // (pixel, sample), so the order inside a block changes no result.  Scenes with Lambertian materials only
     // (FEAT == 0, e.g. C2) have nothing to separate and skip it; C3 +3.8 %, C4 +2.7 %, material_hdr(1) +2.9 %.
-#ifndef RT_SORT_FEAT0
-#define RT_SORT_FEAT0 0
-#endif
     uint32_t slot = bid * blockDim.x + threadIdx.x;
     if (FEAT != 0 || RT_SORT_FEAT0) {
         constexpr uint32_t kCls = RT_SORT_CLASSES;
-        __shared__ uint32_t s_cls[4][kCls];
-        __shared__ uint16_t s_perm[256];
+        __shared__ uint32_t s_cls[kSW][kCls];
+        __shared__ uint16_t s_perm[RT_SHADE_BLOCK];
         uint32_t key = kCls - 1u;
         if (slot < n_active) {
             const uint32_t fl0 = in.flags[slot];
@@ -824,7 +831,7 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc
 #pragma unroll
         for (uint32_t c = 0; c < kCls; c++) {
 #pragma unroll
-            for (uint32_t w = 0; w < 4u; w++) {
+            for (uint32_t w = 0; w < kSW; w++) {
                 const uint32_t cnt = s_cls[w][c];
                 if (c < key || (c == key && w < wave)) dest += cnt;
             }
@@ -840,9 +847,9 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc
     // then ends without pending light terms the slot is marked dead and skipped next bounce
     uint32_t os;
     bool leader = threadIdx.x == 0;
-    __shared__ uint32_t s_alive[4];
+    __shared__ uint32_t s_alive[kSW];
     __shared__ uint32_t s_done;            // waves of the block that have staged their rays
-    __shared__ uint32_t s_stage[4][3][64];  // [wave][kind][rank]: queue entries waiting for the block's reservation
+    __shared__ uint32_t s_stage[kSW][3][64];  // [wave][kind][rank]: queue entries waiting for the block's reservation
     {   // one atomic per block: wave counts -> LDS -> block base -> per-lane slot
         const unsigned long long m = __ballot(a.will_shade);
         // A wave without a vertex to shade -- escaped / fold-only / dead paths, which the dealing step gathers into
@@ -878,7 +885,8 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc
         leader = lane == 0;
         for (uint32_t w = 0; w < wave; w++) leader = leader && s_alive[w] == 0u;
         if (leader) {
-            const uint32_t tot = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0];
+            uint32_t tot = 0;
+            for (uint32_t w = 0; w < kSW; w++) tot += s_cnt[w][0];
             s_base[0] = tot ? atomicAdd(&ctl->n_active[itn], tot) : 0u;
             s_done = 0u;
         }
@@ -916,7 +924,7 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc
             if (r.emit_sh) s_stage[wave][1][__popcll(ms & below0)] = os | (kRayShadow << 30);
             if (r.emit_pr) s_stage[wave][2][__popcll(mp & below0)] = os | (kRayProbe << 30);
             uint32_t n_part = 0;
-            for (uint32_t w = 0; w < 4; w++) n_part += s_alive[w];
+            for (uint32_t w = 0; w < kSW; w++) n_part += s_alive[w];
             // release (every lane: all of them staged entries): this wave's s_stage / s_cnt writes are visible before it is
             // counted; acquire: the last arriver reads the other waves' entries only after it has seen their counts.
             // Workgroup scope, LDS address space only -- the wave's global stores need not have landed.
@@ -931,8 +939,8 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc
                 return;
             }
             // last wave: totals, one reservation, all entries kind by kind ([ext of the waves][shadow ...][probe ...])
-            uint32_t cnt[3][4], tk[3] = {0, 0, 0}, tv = 0;
-            for (uint32_t w = 0; w < 4; w++) {
+            uint32_t cnt[3][kSW], tk[3] = {0, 0, 0}, tv = 0;
+            for (uint32_t w = 0; w < kSW; w++) {
                 const bool al = s_alive[w] != 0u;
                 for (uint32_t k = 0; k < 3; k++) {
                     cnt[k][w] = al ? s_cnt[w][1 + k] : 0u;
@@ -953,7 +961,7 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc
             qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
             uint32_t o = qb;
             for (uint32_t k = 0; k < 3; k++)
-                for (uint32_t w = 0; w < 4; w++) {
+                for (uint32_t w = 0; w < kSW; w++) {
                     if (lane < cnt[k][w]) queue_out[o + lane] = s_stage[w][k][lane];
                     o += cnt[k][w];
                 }
@@ -964,7 +972,7 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc
         __syncthreads();
         if (leader) {
             uint32_t te = 0, tsd = 0, tp = 0, tv = 0;
-            for (int w = 0; w < 4; w++) {
+            for (uint32_t w = 0; w < kSW; w++) {
                 te += s_cnt[w][1];
                 tsd += s_cnt[w][2];
                 tp += s_cnt[w][3];
@@ -985,7 +993,7 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc
         // wave's 128-entry reservation is mostly one kind (shadow rays all run towards the light, probes and
         // extensions anywhere): k_trace -0.6 % (C4) / -2.9 % (C3) / -2.6 % (C2) against wave-by-wave order
         uint32_t oe = s_base[1], osd = 0, op = 0, te = 0, tsd = 0;
-        for (uint32_t w = 0; w < 4; w++) {
+        for (uint32_t w = 0; w < kSW; w++) {
             if (w < wave) {
                 oe += s_cnt[w][1];
                 osd += s_cnt[w][2];
