@@ -28,7 +28,7 @@
 
 #ifndef RT_SHADE_BLOCK
 #define RT_SHADE_BLOCK 256  // threads per k_shade block = the paths dealt among its waves by class.  Measured (profiles/r03_exp_shade_block.txt,
-                            // C4 / C3 k_shade ms): 64: 923 / 123, 128: 644 / 95.4, 192: 613 / 93.6, 256: 616 / 95.0 -- and a dealing window of 2-8
+                            // C4 / C3 k_shade ms): 64: 923 / 123, 128: 644 / 95.4, 192: 613 / 93.6, 256: 616 / 95.0, 384: 759 / 115 -- and a dealing window of 2-8
                             // blocks (tools/experiments/r03_deal_window.patch): 787-1026 / 114-146, the gathered state loads cost more than the
                             // purer waves save
 #endif
