@@ -1397,7 +1397,9 @@ int build_bvh_device(hipStream_t stream, const rt_primitive* d_prims, const DevM
                 }
                 B_TRY(hipMemsetAsync(t.flag, 0, ni * sizeof(uint32_t), stream));
             }
-            (void)sah_top_done;
+            // (more cut elements than the SAH top takes -- beyond ~30 M primitives: the Morton-order tree with the
+            // rotations' default instead)
+            if (!plain_retry && sah_applies && !sah_top_done && !getenv("RT_LBVH_ROTATE_PASSES")) rot_passes = 2;
             hipLaunchKernelGGL(kb_refit, dim3(nb), dim3(256), 0, stream, d_prims, order, (int)n, t, rot_passes > 0 ? 1 : 0);
             for (int pass = 1; pass < rot_passes; pass++) {
                 B_TRY(hipMemsetAsync(t.flag, 0, ni * sizeof(uint32_t), stream));
