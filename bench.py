@@ -151,7 +151,7 @@ ASSETS = "golden"
 class Bench:
     """One workload on this rank's GPU: scene resident, film on the device."""
 
-    def __init__(self, name, rank, world, local_rank, coll_dev, paths_in_flight=0, precision=0):
+    def __init__(self, name, rank, world, local_rank, coll_dev, paths_in_flight=0, precision=0, ctx=None):
         import torch
 
         import rustraytracer_amd as rr
@@ -162,7 +162,9 @@ class Bench:
         if preset in ("material_hdr", "teapot_hdr"):
             kw = dict(kw, mesh_path=asset_dir(ASSETS))
         self.scene = rr.Scene(preset, self.W / self.H, **kw)
-        self.ctx = rr.Context(local_rank)
+        # (the extra rows run on the headline bench's context: one pool of path state per GPU -- 140 GB at the default size)
+        self.own_ctx = ctx is None
+        self.ctx = rr.Context(local_rank) if ctx is None else ctx
         self.gs = self.ctx.upload(self.scene)
         self.info = self.gs.info()
         self.d_rgb = torch.zeros((self.H, self.W, 3), dtype=torch.float64, device="cuda")
@@ -205,7 +207,8 @@ class Bench:
 
     def close(self):
         self.gs.close()
-        self.ctx.close()
+        if self.own_ctx:
+            self.ctx.close()
 
 
 def timed(b, steps, warmup, barrier):
@@ -265,6 +268,13 @@ def roofline(b, acc, stc, steps):
                 source["stale"] = "the profile predates kernel hashing (round 2): figure kept, build unverified"
             elif now is None or now["sha256"] != prof_hash:
                 source["stale"] = "k_trace was rebuilt since the profile was taken: counter figures withheld"
+            else:
+                # bytes per LAUNCH only carry over when a step is cut into the same launches (pool size, batch size)
+                prof_lps = float(rec.get("launches") or 0) / max(float(rec.get("steps_profiled") or 1), 1.0)
+                source["profile_launches_per_step"] = prof_lps
+                if prof_lps and abs(prof_lps - launches_per_step) > 0.05 * prof_lps:
+                    source["stale"] = ("the profile was taken with %.0f k_trace launches per step, this run has %.0f "
+                                       "(pool / batch size): counter figures withheld" % (prof_lps, launches_per_step))
             if source["stale"] is None or prof_hash is None:
                 traffic = float(rec.get("hbm_bytes_per_launch"))
                 traffic_step = traffic * launches_per_step
@@ -407,7 +417,7 @@ def main():
         # the smaller single-GPU configs, same accounting (they are parity-test cases, not the headline)
         extra = []
         for name in ("c2", "c3"):
-            e = Bench(name, 0, 1, local_rank, coll_dev, args.paths_in_flight)
+            e = Bench(name, 0, 1, local_rank, coll_dev, args.paths_in_flight, ctx=b.ctx)
             ea = timed(e, 2 if name == "c3" else 5, 1, barrier)
             esteps = 2 if name == "c3" else 5
             ec = e.counted()
@@ -419,7 +429,7 @@ def main():
                           "k_shade_ms_per_step": ea["shade_ms"] / esteps, "k_trace_ms_per_step": ea["trace_ms"] / esteps})
             e.close()
         # the f32 fast mode on the headline workload: reported, never the headline (SURVEY.md 8d tolerance row)
-        f = Bench(args.workload, 0, 1, local_rank, coll_dev, args.paths_in_flight, precision=1)
+        f = Bench(args.workload, 0, 1, local_rank, coll_dev, args.paths_in_flight, precision=1, ctx=b.ctx)
         fa = timed(f, 2, 1, barrier)
         img32 = (f.d_rgb / f.d_n[..., None].clamp(min=1)).clamp(0.0, 10.0)
         b.step()

@@ -136,7 +136,9 @@ static int ensure_lane_capacity(rt_context* c, Lane& ln, uint32_t cap) {
     // one slab: 2 x (27 double arrays, rng, 4 result arrays, flags, orig), 2 ray queues
     const size_t n = cap;
     const size_t bytes = n * (2 * (27 * 8 + 8 + 4 * 4 + 4 + 4) + 2 * 3 * 4) + 4096;
-    HIP_TRY(hipMalloc(&ln.pool, bytes));
+    void* slab = nullptr;
+    HIP_TRY(hipMalloc(&slab, bytes));  // (on failure ln.pool stays null and ln.capacity 0: the caller may retry smaller)
+    ln.pool = slab;
     char* p = (char*)ln.pool;
     for (int b = 0; b < 2; b++) {
         PathState& st = ln.st[b];
@@ -1253,16 +1255,24 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
         }
         const size_t batch_cap = (size_t)PB * ns;
         // pool per lane
-        // default pool: 64 Mi paths (33 GB of path state when a batch is that large; smaller batches size it down).
-        // Fewer, fuller launches: C3 -3.5 %, C4 -4.6 % against 16 Mi.
-        uint32_t P = cfg->paths_in_flight ? cfg->paths_in_flight : (1u << 26);
-        P = std::max<uint32_t>(64u, std::min<uint32_t>(P, 1u << 26));
+        // default pool: 256 Mi paths = a whole batch (140 GB of path state of the 288 GB when a batch is that large; smaller
+        // batches size it down).  Fewer, fuller launches: C4 3822 / 4077 / 4105 / 4206 Mrays/s at 16 / 64 / 128 / 256 Mi,
+        // C3 3910 / 4090 / 4141 / 4185 (profiles/r03_sweep_pool.txt, r03_sweep_pool_big.txt).  A default that does not fit
+        // the memory that is free is halved (down to 16 Mi) instead of failing; a size the caller asked for is not.
+        const bool pool_default = cfg->paths_in_flight == 0;
+        uint32_t P = pool_default ? (1u << 28) : cfg->paths_in_flight;
+        P = std::max<uint32_t>(64u, std::min<uint32_t>(P, 1u << 28));
         P = (P + 63u) & ~63u;
-        const int n_lanes = (batch_cap > (size_t)P) ? c->n_lanes : 1;
-        P = (uint32_t)std::min<size_t>(P, (batch_cap + 63) & ~(size_t)63);
-        for (int i = 0; i < n_lanes; i++) {
-            int rc = ensure_lane_capacity(c, c->lanes[i], P);
-            if (rc != RT_OK) return rc;
+        int n_lanes = 1;
+        for (;;) {
+            n_lanes = (batch_cap > (size_t)P) ? c->n_lanes : 1;
+            P = (uint32_t)std::min<size_t>(P, (batch_cap + 63) & ~(size_t)63);
+            int rc = RT_OK;
+            for (int i = 0; i < n_lanes && rc == RT_OK; i++) rc = ensure_lane_capacity(c, c->lanes[i], P);
+            if (rc == RT_OK) break;
+            if (rc != RT_ERR_OOM || !pool_default || P <= (1u << 24)) return rc;
+            (void)hipGetLastError();
+            P >>= 1;
         }
         if (c->lf_capacity < batch_cap) {
             if (c->lf[0]) HIP_TRY(hipFree(c->lf[0]));

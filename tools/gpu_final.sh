@@ -6,7 +6,7 @@ timeout 1800 python -m pytest tests -q -m gpu > gpurun_out/${R}_gputests.log 2>&
 for wl in c4 c3 c2; do bash tools/refresh_profiles.sh $wl > gpurun_out/${R}_refresh_$wl.log 2>&1; echo "refresh $wl rc=$?"; done
 python bench.py > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.err; echo "default bench rc=$?"
 for wl in c5 c3p hdr hdr1 teapot; do
-  extra=""; [ $wl = c5 ] && extra="--steps 1 --warmup 0"
+  extra=""; [ $wl = c5 ] && extra="--steps 1 --warmup 1"
   python bench.py --workload $wl --no-cpu-baseline --no-extra $extra > gpurun_out/${R}_bench_$wl.json 2> gpurun_out/${R}_bench_$wl.err; echo "bench $wl rc=$?"
 done
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --backend gloo --workload c3 --steps 2 --warmup 1 > gpurun_out/${R}_bench_c3_2ranks_gloo_one_gpu.json 2> gpurun_out/${R}_bench_2ranks.err; echo "2-rank gloo bench rc=$?"
