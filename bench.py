@@ -399,6 +399,8 @@ def main():
                        "triangles": b.info["n_triangles"], "bvh_nodes": b.info["n_bvh_nodes"],
                        "rays_per_step": rays_all / args.steps, "paths_per_step": W * H * spp,
                        "parallelism": f"tiles{world}", "bvh_from_shared_cache": bool(b.info.get("build_from_cache", 0)),
+                       # path-state slots kept alive per GPU (520 B each): the library default is a whole batch, <= 2^28
+                       "paths_in_flight": args.paths_in_flight or "library default: min(batch, 2^28) = 140 GB of path state at most",
                        "scene_commit_ms": b.info.get("build_ms")},
             "roofline": roofline(b, acc, stc, args.steps),
             "device_ms_per_step": acc["kernel_ms"] / args.steps,
