@@ -125,8 +125,19 @@ struct rt_scene {
     std::vector<rt_scene*> replicas;  // multi-device context: the device copies on ctx->peers[i] (no host data)
 };
 
+// (test hook: RT_TEST_POOL_OOM_ABOVE=<log2> makes pools of more than 2^log2 paths fail as if the memory were not
+// there, so that tests/test_gpu_abi2.py can walk the default pool's fall-back without 288 GB of other allocations)
+static uint32_t test_pool_oom_above() {
+    static const uint32_t v = [] {
+        const char* e = getenv("RT_TEST_POOL_OOM_ABOVE");
+        return e ? (1u << std::min(28, std::max(6, atoi(e)))) : 0u;
+    }();
+    return v;
+}
+
 static int ensure_lane_capacity(rt_context* c, Lane& ln, uint32_t cap) {
     if (ln.capacity >= cap) return RT_OK;
+    if (test_pool_oom_above() && cap > test_pool_oom_above()) return fail(RT_ERR_OOM, "simulated: no memory for a pool of %u paths", cap);
     HIP_TRY(hipSetDevice(c->device));
     if (ln.pool) {
         HIP_TRY(hipFree(ln.pool));
@@ -1255,6 +1266,16 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
         }
         const size_t batch_cap = (size_t)PB * ns;
         // pool per lane
+        // (the film staging first: what the pool's default may take is what is left after it)
+        if (c->lf_capacity < batch_cap) {
+            if (c->lf[0]) HIP_TRY(hipFree(c->lf[0]));
+            c->lf[0] = c->lf[1] = c->lf[2] = nullptr;
+            c->lf_capacity = 0;
+            HIP_TRY(hipMalloc((void**)&c->lf[0], batch_cap * 3 * sizeof(double)));
+            c->lf[1] = c->lf[0] + batch_cap;
+            c->lf[2] = c->lf[1] + batch_cap;
+            c->lf_capacity = batch_cap;
+        }
         // default pool: 256 Mi paths = a whole batch (140 GB of path state of the 288 GB when a batch is that large; smaller
         // batches size it down).  Fewer, fuller launches: C4 3822 / 4077 / 4105 / 4206 Mrays/s at 16 / 64 / 128 / 256 Mi,
         // C3 3910 / 4090 / 4141 / 4185 (profiles/r03_sweep_pool.txt, r03_sweep_pool_big.txt).  A default that does not fit
@@ -1270,18 +1291,10 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
             int rc = RT_OK;
             for (int i = 0; i < n_lanes && rc == RT_OK; i++) rc = ensure_lane_capacity(c, c->lanes[i], P);
             if (rc == RT_OK) break;
-            if (rc != RT_ERR_OOM || !pool_default || P <= (1u << 24)) return rc;
+            const uint32_t floor_paths = test_pool_oom_above() ? 64u : (1u << 24);
+            if (rc != RT_ERR_OOM || !pool_default || P <= floor_paths) return rc;
             (void)hipGetLastError();
             P >>= 1;
-        }
-        if (c->lf_capacity < batch_cap) {
-            if (c->lf[0]) HIP_TRY(hipFree(c->lf[0]));
-            c->lf[0] = c->lf[1] = c->lf[2] = nullptr;
-            c->lf_capacity = 0;
-            HIP_TRY(hipMalloc((void**)&c->lf[0], batch_cap * 3 * sizeof(double)));
-            c->lf[1] = c->lf[0] + batch_cap;
-            c->lf[2] = c->lf[1] + batch_cap;
-            c->lf_capacity = batch_cap;
         }
         RenderJob job;
         job.c = c;

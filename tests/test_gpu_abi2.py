@@ -400,3 +400,48 @@ def test_plain_c_host_renders_the_same_film(gpu_ctx, tmp_path):
     assert int(got["rays"]) == st.rays
     from tests.test_host_cpu import _read_png
     assert np.array_equal(_read_png(png), gpu_ctx.resolve_rgb8(rgb, n))
+
+
+@pytest.mark.gpu
+def test_default_pool_falls_back_when_memory_is_short(gpu_ctx):
+    """rt_render_cfg.paths_in_flight = 0 asks for a whole batch of path state (up to 2^28 slots, 140 GB): when that does not
+    fit, the library halves the DEFAULT until it does and renders the same film; a size the caller asked for is never
+    changed -- it fails with RT_ERR_OOM.  The shortage is simulated (abi.hip: RT_TEST_POOL_OOM_ABOVE, read once per
+    process, hence the child processes)."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import hashlib, sys
+sys.path.insert(0, %r)
+import numpy as np
+import rustraytracer_amd as rr
+sc = rr.cornell_box_statue(mesh_faces=3000, variant=1)
+ctx = rr.Context(0)
+gs = ctx.upload(sc)
+pif = int(sys.argv[1])
+try:
+    r, n, st = ctx.render(gs, sc.camera, rr.make_cfg(192, 160, 16, seed=5, paths_in_flight=pif))
+    print("film", hashlib.sha256(r.tobytes() + n.tobytes()).hexdigest(), st.rays)
+except Exception as e:
+    print("error", type(e).__name__, str(e)[:200])
+''' % root
+    sc = rr.cornell_box_statue(mesh_faces=3000, variant=1)
+    gs = gpu_ctx.upload(sc)
+    r, n, st = gpu_ctx.render(gs, sc.camera, rr.make_cfg(192, 160, 16, seed=5))
+    gs.close()
+    want = "film %s %d" % (hashlib.sha256(r.tobytes() + n.tobytes()).hexdigest(), st.rays)
+
+    def child(pif):
+        env = dict(os.environ, RT_TEST_POOL_OOM_ABOVE="15")  # pools above 32768 paths "do not fit"
+        out = subprocess.run([sys.executable, "-c", code, str(pif)], env=env, capture_output=True, text=True, timeout=300)
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith(("film", "error"))]
+        assert lines, out.stderr[-800:]
+        return lines[-1]
+
+    # 192 x 160 x 16 = 491520 camera samples: the default pool (a whole batch) is halved four times down to 30720 paths
+    assert child(0) == want
+    got = child(491520)
+    assert got.startswith("error") and "memory" in got.lower(), got
