@@ -1094,15 +1094,23 @@ static int run_lane(RenderJob& job, int lane_id) {
         }
         return job.abort.load();
     };
+    // How far the host runs ahead of the counters it sizes the grids from (they never grow): k_shade's grid for iteration
+    // `it` covers the paths that were alive `lag` iterations earlier, and every block beyond the live ones costs ~2 ns of
+    // dispatch.  RT_MIRROR_LAG=1 against the default 2: C4 +0.3 %, C3 +0.2 %, C2 -1.5 % (the launch latency shows on
+    // small frames) -- profiles/r03_sweep_mirror_lag.txt.
+    static const unsigned long long lag = [] {
+        const char* e = getenv("RT_MIRROR_LAG");
+        return (unsigned long long)(e ? std::min(4, std::max(1, atoi(e))) : 2);
+    }();
     for (; it < max_iters; it++) {
         if (poll_cancel()) return RT_ERR_HIP;
         static const bool no_mirror = getenv("RT_NO_MIRROR") != nullptr;  // experiment: fixed iteration count
         if (no_mirror) {
             if (it > (unsigned long long)cfg->max_depth + 2) break;
-        } else if (it >= 2) {
-            // counters published when k_trace(it-2) started; two iterations stay queued behind it
-            volatile MirrorEntry* me = &ln.mirror_h[(it - 2) % kRing];
-            const uint32_t want_seq = seq0 + (uint32_t)(it - 2);
+        } else if (it >= lag) {
+            // counters published when k_trace(it - lag) started; `lag` iterations stay queued behind it
+            volatile MirrorEntry* me = &ln.mirror_h[(it - lag) % kRing];
+            const uint32_t want_seq = seq0 + (uint32_t)(it - lag);
             const auto t0 = std::chrono::steady_clock::now();
             uint64_t spins = 0;
             // The wait is normally a few microseconds (the device runs two iterations ahead of this read): spin
@@ -1116,7 +1124,7 @@ static int run_lane(RenderJob& job, int lane_id) {
                 if (poll_cancel()) return RT_ERR_HIP;
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
                     job.abort.store(true);
-                    return lane_fail(ln, RT_ERR_HIP, "device did not publish iteration %llu counters within 30 s", it - 2);
+                    return lane_fail(ln, RT_ERR_HIP, "device did not publish iteration %llu counters within 30 s", it - lag);
                 }
             }
             const uint32_t live = me->n_active, rem = me->remaining;
