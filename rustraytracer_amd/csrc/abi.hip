@@ -794,12 +794,28 @@ static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cac
         } bvh;
         {
             Bvh8Out b8;
-            build_bvh8(s->prims.data(), s->prims.size(), b8);
+            build_bvh8(s->prims.data(), s->prims.size(), b8, RT_BVH8 == 2 ? 4 : 8);
             if (b8.stack_need + 2 > (uint32_t)(kLdsStack + kOvfStack))
                 return fail(RT_ERR_UNSUPPORTED, "BVH8 stack need %u exceeds the traversal stack", b8.stack_need);
             static_assert(sizeof(DevNode) == sizeof(DevNode8), "node records share the array");
+#if RT_BVH8 == 2
+            // the 4-wide variant: 64-B records (geom.h: node_step), two per DevNode-sized element of the array
+            bvh.nodes.assign((b8.nodes.size() + 1) / 2, DevNode{});
+            for (size_t i = 0; i < b8.nodes.size(); i++) {
+                const DevNode8& nd = b8.nodes[i];
+                unsigned char* o = reinterpret_cast<unsigned char*>(bvh.nodes.data()) + i * 64;
+                std::memcpy(o, &nd.ox, 12);
+                o[12] = nd.ex; o[13] = nd.ey; o[14] = nd.ez; o[15] = nd.nv;
+                std::memcpy(o + 16, &nd.child_base, 4);
+                std::memcpy(o + 20, &nd.leaf_base, 4);
+                o[24] = nd.ni; o[25] = nd.nt; o[26] = o[27] = 0;
+                for (int a = 0; a < 6; a++)
+                    for (int k = 0; k < 4; k++) o[28 + 4 * a + k] = nd.q[a][k];
+            }
+#else
             bvh.nodes.resize(b8.nodes.size());
             std::memcpy(bvh.nodes.data(), b8.nodes.data(), b8.nodes.size() * sizeof(DevNode8));
+#endif
             bvh.order = std::move(b8.order);
             bvh.depth = b8.depth;
             if (getenv("RT_DIAG"))

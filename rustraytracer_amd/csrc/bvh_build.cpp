@@ -568,6 +568,7 @@ struct Collapser8 {
     uint32_t max_depth = 0;
     double area_q = 0.0, area_x = 0.0;
     double open_ratio = getenv("RT_BVH8_OPEN_RATIO") ? atof(getenv("RT_BVH8_OPEN_RATIO")) : 256.0;
+    int width = 8;  // children per node (4: the 64-B variant, RT_BVH8 = 2)
     Collapser8(const std::vector<BinNode>& b, const uint32_t* oi, const rt_primitive* p, std::vector<DevNode8>& n,
                std::vector<uint32_t>& o)
         : bin(b), order_in(oi), prims(p), nodes(n), order(o) {}
@@ -615,7 +616,7 @@ struct Collapser8 {
         // on THIS node's 8-bit grid, and e.g. the dragons' subtrees on the grid of a root that also holds the 2e4-wide
         // floor (cell size 128) would all be hit by every ray.  Such a child stays a node of its own, with its own grid.
         const double open_min_area = bin[bi].box.half_area() / open_ratio;
-        while (nk < 8) {
+        while (nk < width) {
             int best = -1;
             double best_area = -1.0;
             for (int k = 0; k < nk; k++)
@@ -685,7 +686,7 @@ struct Collapser8 {
 };
 }  // namespace
 
-void build_bvh8(const rt_primitive* prims, size_t n, Bvh8Out& out) {
+void build_bvh8(const rt_primitive* prims, size_t n, Bvh8Out& out, int width) {
     out = Bvh8Out{};
     if (n == 0) return;
     for (uint32_t cap : {64u, 16u, 8u, 0u}) {
@@ -698,6 +699,7 @@ void build_bvh8(const rt_primitive* prims, size_t n, Bvh8Out& out) {
         out.nodes.reserve(bd.bin.size() / 4 + 2);
         out.order.reserve(n);
         Collapser8 col(bd.bin, bd.order, prims, out.nodes, out.order);
+        col.width = width;
         out.nodes.resize(1);
         if (bd.bin[root].is_leaf) {  // a single primitive: node 0 is always internal
             DevNode8 nd;

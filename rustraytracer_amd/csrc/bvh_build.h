@@ -26,7 +26,7 @@ struct Bvh8Out {
     uint32_t stack_need = 0;
     double quant_area_ratio = 0.0;  // diagnostic: sum of decoded child areas / sum of exact child areas
 };
-void build_bvh8(const rt_primitive* prims, size_t n, Bvh8Out& out);
+void build_bvh8(const rt_primitive* prims, size_t n, Bvh8Out& out, int width = 8);  // width 4: RT_BVH8 = 2 (64-B nodes)
 
 // Binned-SAH BINARY tree over n boxes (6 doubles each: min xyz, max xyz), one box per leaf -- the top of the device
 // builder's tree (bvh_gpu.hip: clusters of the Morton-order tree become the leaves).  Internal nodes are numbered

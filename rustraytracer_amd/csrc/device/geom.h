@@ -482,7 +482,9 @@ struct TravCount {
 #define RT_TRACE_WAVES 5
 #endif
 #ifndef RT_BVH8
-#define RT_BVH8 0  // (experiment, round 3) 1: the 8-wide tree with 8-bit child boxes (scene_dev.h: DevNode8) replaces the BVH4
+#define RT_BVH8 0  // (experiment, round 3) 1: the 8-wide tree with 8-bit child boxes (scene_dev.h: DevNode8) replaces the BVH4;
+                   // 2: the 4-wide tree with 8-bit boxes in 64-B records (build with -DRT_LDS_NODES=0).  Both measured slower:
+                   // profiles/r03_exp_bvh8_q8*.txt, r03_exp_q4_nodes.txt
 #endif
 constexpr int kLdsStack = RT_LDS_STACK;
 #if RT_BVH8
@@ -745,7 +747,88 @@ RTD void node_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
 }
 #endif  // !RT_BVH8
 
-#if RT_BVH8
+#if RT_BVH8 == 2
+// ---- experiment RT_BVH8 = 2: the 4-wide tree with 8-bit child boxes in a 64-B record, FOUR 16-B loads per visit instead
+// of seven and half the bytes (abi.hip packs build_bvh8(width 4)'s nodes):
+//   [ 0,16) grid origin x y z (f32), {ex, ey, ez, nv}      [16,32) child_base, leaf_base, {ni, nt, 0, 0}, lo_x[4]
+//   [32,48) lo_y[4] lo_z[4] hi_x[4] hi_y[4]                [48,52) hi_z[4]
+// Arithmetic, slack and child references as in the 8-wide node below; the key carries the slot in its low TWO bits.
+template <bool COUNT>
+RTD void node_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
+    const char* nb = reinterpret_cast<const char*>(sc.nodes) + (size_t)(uint32_t)tv.cur * 64u;
+    const uint4 h0 = *reinterpret_cast<const uint4*>(nb);
+    const uint4 h1 = *reinterpret_cast<const uint4*>(nb + 16u);
+    const uint4 qa = *reinterpret_cast<const uint4*>(nb + 32u);  // lo_y lo_z hi_x hi_y
+    const uint32_t qhz = *reinterpret_cast<const uint32_t*>(nb + 48u);
+    if (COUNT) tc->nodes++;
+    const float tmin32 = float_lower(tv.tmin);
+    const float tmax32 = (float)tv.tmax * (1.0f + kNodeSlack);
+    const float lim32 = __builtin_fminf((float)prune_limit(tv) * (1.0f + kNodeSlack), tmax32);
+    const float ox = __uint_as_float(h0.x), oy = __uint_as_float(h0.y), oz = __uint_as_float(h0.z);
+    const float cx = __uint_as_float((h0.w & 0xffu) << 23), cy = __uint_as_float(((h0.w >> 8) & 0xffu) << 23),
+                cz = __uint_as_float(((h0.w >> 16) & 0xffu) << 23);
+    const uint32_t nv = h0.w >> 24;
+    const float sx = cx * tv.ix, sy = cy * tv.iy, sz = cz * tv.iz;
+    float bnx = __builtin_fmaf(ox, tv.ix, tv.cnx), bny = __builtin_fmaf(oy, tv.iy, tv.cny), bnz = __builtin_fmaf(oz, tv.iz, tv.cnz);
+    float bfx = __builtin_fmaf(ox, tv.ix, tv.cfx), bfy = __builtin_fmaf(oy, tv.iy, tv.cfy), bfz = __builtin_fmaf(oz, tv.iz, tv.cfz);
+    bnx = __builtin_fmaf(-__builtin_fabsf(bnx), kNodeSlack, bnx);
+    bny = __builtin_fmaf(-__builtin_fabsf(bny), kNodeSlack, bny);
+    bnz = __builtin_fmaf(-__builtin_fabsf(bnz), kNodeSlack, bnz);
+    bfx = __builtin_fmaf(__builtin_fabsf(bfx), kNodeSlack, bfx);
+    bfy = __builtin_fmaf(__builtin_fabsf(bfy), kNodeSlack, bfy);
+    bfz = __builtin_fmaf(__builtin_fabsf(bfz), kNodeSlack, bfz);
+    const bool ngx = (__float_as_uint(tv.ix) >> 31) != 0u, ngy = (__float_as_uint(tv.iy) >> 31) != 0u,
+               ngz = (__float_as_uint(tv.iz) >> 31) != 0u;
+    const uint32_t lox = h1.w, loy = qa.x, loz = qa.y, hix = qa.z, hiy = qa.w, hiz = qhz;
+    const uint32_t nx = ngx ? hix : lox, fx = ngx ? lox : hix;
+    const uint32_t ny = ngy ? hiy : loy, fy = ngy ? loy : hiy;
+    const uint32_t nz = ngz ? hiz : loz, fz = ngz ? loz : hiz;
+    const uint32_t ni = h1.z & 0xffu, nt = (h1.z >> 8) & 0xffu;
+#define RT_Q(w, k) ((float)(((w) >> (8 * (k))) & 0xffu))
+#define RT_NODE4Q_CHILD(k, key)                                                                            \
+    uint32_t key;                                                                                          \
+    {                                                                                                      \
+        const float m_ = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(RT_Q(nx, k), sx, bnx),             \
+                                                         __builtin_fmaf(RT_Q(ny, k), sy, bny)),            \
+                                         __builtin_fmaf(RT_Q(nz, k), sz, bnz));                            \
+        const float f_ = __builtin_fminf(__builtin_fminf(__builtin_fmaf(RT_Q(fx, k), sx, bfx),             \
+                                                         __builtin_fmaf(RT_Q(fy, k), sy, bfy)),            \
+                                         __builtin_fmaf(RT_Q(fz, k), sz, bfz));                            \
+        const float e_ = __builtin_fmaxf(__builtin_fmaf(-__builtin_fabsf(m_), kNodeSlack, m_), tmin32);     \
+        const float x_ = __builtin_fminf(__builtin_fmaf(__builtin_fabsf(f_), kNodeSlack, f_), lim32);      \
+        key = (e_ <= x_ && (uint32_t)(k) < nv) ? ((__float_as_uint(e_) & 0x7ffffffcu) | (uint32_t)(k)) : 0xffffffffu; \
+    }
+    RT_NODE4Q_CHILD(0, k0)
+    RT_NODE4Q_CHILD(1, k1)
+    RT_NODE4Q_CHILD(2, k2)
+    RT_NODE4Q_CHILD(3, k3)
+#undef RT_NODE4Q_CHILD
+#undef RT_Q
+#define RT_KSWAP(a, b)                                \
+    {                                                 \
+        const uint32_t lo_ = a < b ? a : b;           \
+        b = a < b ? b : a;                            \
+        a = lo_;                                      \
+    }
+    RT_KSWAP(k0, k1) RT_KSWAP(k2, k3) RT_KSWAP(k0, k2) RT_KSWAP(k1, k3) RT_KSWAP(k1, k2)
+#undef RT_KSWAP
+    if (k0 == 0xffffffffu) {
+        trav_pop(tv, ts);
+        return;
+    }
+    const uint32_t cbase = h1.x, lbase = h1.y - ni;  // leaf slot of child `slot` = lbase + slot
+    auto child_ref = [&](uint32_t key) -> int32_t {
+        const uint32_t slot = key & 3u;
+        const uint32_t leaf = ((lbase + slot) << 3) | (slot >= nt ? kLeafCodeOther : 0u);
+        return slot < ni ? (int32_t)(cbase + slot) : -1 - (int32_t)leaf;
+    };
+    // farthest first, so that the nearest pending child is on top of the stack
+    if (k3 != 0xffffffffu) { stack_push(ts, tv.sp, child_ref(k3), __uint_as_float(k3 & 0x7ffffffcu)); tv.sp++; }
+    if (k2 != 0xffffffffu) { stack_push(ts, tv.sp, child_ref(k2), __uint_as_float(k2 & 0x7ffffffcu)); tv.sp++; }
+    if (k1 != 0xffffffffu) { stack_push(ts, tv.sp, child_ref(k1), __uint_as_float(k1 & 0x7ffffffcu)); tv.sp++; }
+    tv.cur = child_ref(k0);
+}
+#elif RT_BVH8
 // ---- experiment RT_BVH8: one 8-wide node with 8-bit child boxes (scene_dev.h: DevNode8), five 16-B loads.
 // plane = origin + q * 2^e, so the ray parameter of a plane is
 //     t = (plane - o) / d = q * (2^e * inv) + (origin - o) * inv  ~  fma(q, s, b),   s = 2^e * inv32 (exact scaling),
