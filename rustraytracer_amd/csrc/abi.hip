@@ -762,9 +762,6 @@ static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cac
     for (const auto& m : s->meshes) any_normals = any_normals || !m.n.empty();
     if (np >= kMetaMatMask || s->mats.size() >= kMetaMatMask) return fail(RT_ERR_UNSUPPORTED, "too many primitives or materials");
     const auto t0 = std::chrono::steady_clock::now();
-#if RT_BVH8
-    flags &= ~(uint32_t)RT_COMMIT_DEVICE_LBVH;  // (experiment build) the 8-wide tree only comes from the host builder
-#endif
     if (flags & RT_COMMIT_DEVICE_LBVH) {
         // next-row f3: the tree is built where the primitives already are (bvh_gpu.hip)
         DeviceBvh gb;
@@ -785,48 +782,9 @@ static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cac
         t->info.build_device_ms = gb.build_ms;
     } else {
         if (!cache.valid) {
-#if RT_BVH8
-        // experiment RT_BVH8: the 8-wide tree with 8-bit boxes (scene_dev.h: DevNode8); `nodes` carries its 128-B records
-        struct {
-            std::vector<DevNode> nodes;
-            std::vector<uint32_t> order;
-            uint32_t depth = 0;
-        } bvh;
-        {
-            Bvh8Out b8;
-            build_bvh8(s->prims.data(), s->prims.size(), b8, RT_BVH8 == 2 ? 4 : 8);
-            if (b8.stack_need + 2 > (uint32_t)(kLdsStack + kOvfStack))
-                return fail(RT_ERR_UNSUPPORTED, "BVH8 stack need %u exceeds the traversal stack", b8.stack_need);
-            static_assert(sizeof(DevNode) == sizeof(DevNode8), "node records share the array");
-#if RT_BVH8 == 2
-            // the 4-wide variant: 64-B records (geom.h: node_step), two per DevNode-sized element of the array
-            bvh.nodes.assign((b8.nodes.size() + 1) / 2, DevNode{});
-            for (size_t i = 0; i < b8.nodes.size(); i++) {
-                const DevNode8& nd = b8.nodes[i];
-                unsigned char* o = reinterpret_cast<unsigned char*>(bvh.nodes.data()) + i * 64;
-                std::memcpy(o, &nd.ox, 12);
-                o[12] = nd.ex; o[13] = nd.ey; o[14] = nd.ez; o[15] = nd.nv;
-                std::memcpy(o + 16, &nd.child_base, 4);
-                std::memcpy(o + 20, &nd.leaf_base, 4);
-                o[24] = nd.ni; o[25] = nd.nt; o[26] = o[27] = 0;
-                for (int a = 0; a < 6; a++)
-                    for (int k = 0; k < 4; k++) o[28 + 4 * a + k] = nd.q[a][k];
-            }
-#else
-            bvh.nodes.resize(b8.nodes.size());
-            std::memcpy(bvh.nodes.data(), b8.nodes.data(), b8.nodes.size() * sizeof(DevNode8));
-#endif
-            bvh.order = std::move(b8.order);
-            bvh.depth = b8.depth;
-            if (getenv("RT_DIAG"))
-                fprintf(stderr, "[rt diag] bvh8: %zu nodes, depth %u, stack need %u, decoded/exact child area %.4f\n",
-                        bvh.nodes.size(), b8.depth, b8.stack_need, b8.quant_area_ratio);
-        }
-#else
         BvhOut bvh;
         t->info.build_from_cache = (uint32_t)build_bvh_shared(s->prims.data(), s->prims.size(), bvh);
         if (bvh.depth + 1 > (uint32_t)kMaxBvhDepth) return fail(RT_ERR_UNSUPPORTED, "BVH depth %u exceeds the traversal stack", bvh.depth);
-#endif
         // leaf-ordered triangle vertices + ids
         std::vector<uint32_t>& leaf_prim = cache.leaf_prim;
         std::vector<double>& leaf_tri = cache.leaf_tri;
@@ -873,9 +831,7 @@ static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cac
         }
         const uint64_t n_tri_host = n_tri_atomic.load();
         cache.nodes = std::move(bvh.nodes);
-#if !RT_BVH8
         top_of_tree_first(cache.nodes, 256);
-#endif
         if (getenv("RT_DIAG"))
             fprintf(stderr, "[rt diag] commit: tree + leaf arrays on the host %.1f ms\n",
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
@@ -916,11 +872,7 @@ static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cac
     t->info.n_others = np - n_tri;
     t->info.n_bvh_nodes = d.n_nodes;
     t->info.bvh_depth = depth;
-#if RT_BVH8
-    t->info.node_bytes = 80;  // bytes a node visit requests: five 16-B loads of the 128-B record
-#else
     t->info.node_bytes = sizeof(DevNode);
-#endif
     // bytes a primitive test requests from its leaf_trav line: the nine coordinates / v[5] + meta, + the index word
     t->info.tri_bytes = 9 * sizeof(double) + sizeof(uint32_t);
     t->info.other_bytes = 6 * sizeof(double) + sizeof(uint32_t);

@@ -557,181 +557,6 @@ static void build_once(const rt_primitive* prims, size_t n, uint32_t sah_depth_c
     out.order = std::move(bd.order_store);
 }
 
-// ---- experiment RT_BVH8: 8-wide collapse with 8-bit boxes on the node's grid (scene_dev.h: DevNode8)
-namespace {
-struct Collapser8 {
-    const std::vector<BinNode>& bin;
-    const uint32_t* order_in;       // the binary builder's primitive order (leaf_ref indexes it)
-    const rt_primitive* prims;
-    std::vector<DevNode8>& nodes;
-    std::vector<uint32_t>& order;   // new leaf order
-    uint32_t max_depth = 0;
-    double area_q = 0.0, area_x = 0.0;
-    double open_ratio = getenv("RT_BVH8_OPEN_RATIO") ? atof(getenv("RT_BVH8_OPEN_RATIO")) : 256.0;
-    int width = 8;  // children per node (4: the 64-B variant, RT_BVH8 = 2)
-    Collapser8(const std::vector<BinNode>& b, const uint32_t* oi, const rt_primitive* p, std::vector<DevNode8>& n,
-               std::vector<uint32_t>& o)
-        : bin(b), order_in(oi), prims(p), nodes(n), order(o) {}
-
-    static void quantise_axis(const Box* kb, int nk, int a, float& origin, uint8_t& ebits, uint8_t* qlo, uint8_t* qhi) {
-        double lo = std::numeric_limits<double>::infinity(), hi = -lo;
-        for (int k = 0; k < nk; k++) {
-            lo = std::min(lo, kb[k].mn[a]);
-            hi = std::max(hi, kb[k].mx[a]);
-        }
-        origin = f_down(lo);
-        const double org = (double)origin;
-        int e = -126;
-        const double ext = hi - org;
-        if (ext > 0.0) {
-            int fe;
-            (void)std::frexp(ext / 255.0, &fe);  // ext / 255 = m * 2^fe, m in [0.5, 1)  ->  2^fe >= ext / 255
-            e = std::max(-126, std::min(127, fe));
-        }
-        for (;; e++) {  // (rounding of the sum: make sure the last plane reaches the upper end)
-            const double cell = std::ldexp(1.0, e);
-            if (org + 255.0 * cell >= hi || e >= 127) break;
-        }
-        const double cell = std::ldexp(1.0, e);
-        ebits = (uint8_t)(e + 127);
-        for (int k = 0; k < nk; k++) {
-            double ql = std::floor((kb[k].mn[a] - org) / cell), qh = std::ceil((kb[k].mx[a] - org) / cell);
-            ql = std::min(255.0, std::max(0.0, ql));
-            qh = std::min(255.0, std::max(0.0, qh));
-            while (ql > 0.0 && org + ql * cell > kb[k].mn[a]) ql -= 1.0;
-            while (qh < 255.0 && org + qh * cell < kb[k].mx[a]) qh += 1.0;
-            qlo[k] = (uint8_t)ql;
-            qhi[k] = (uint8_t)qh;
-        }
-    }
-
-    // fills nodes[me] from the internal binary node bi; returns the stack depth a traversal below it can need
-    uint32_t emit(int32_t bi, uint32_t me, uint32_t depth) {
-        max_depth = std::max(max_depth, depth);
-        int32_t kids[8];
-        int nk = 0;
-        kids[nk++] = bin[bi].left;
-        kids[nk++] = bin[bi].right;
-        // A child is only opened into this node while it is not small against the node: its children would be stored
-        // on THIS node's 8-bit grid, and e.g. the dragons' subtrees on the grid of a root that also holds the 2e4-wide
-        // floor (cell size 128) would all be hit by every ray.  Such a child stays a node of its own, with its own grid.
-        const double open_min_area = bin[bi].box.half_area() / open_ratio;
-        while (nk < width) {
-            int best = -1;
-            double best_area = -1.0;
-            for (int k = 0; k < nk; k++)
-                if (!bin[kids[k]].is_leaf) {
-                    double a = bin[kids[k]].box.half_area();
-                    if (a > best_area && a >= open_min_area) {
-                        best_area = a;
-                        best = k;
-                    }
-                }
-            if (best < 0) break;
-            const int32_t c = kids[best];
-            kids[best] = bin[c].left;
-            kids[nk++] = bin[c].right;
-        }
-        // internal children first, then triangle leaves, then sphere / rect leaves
-        auto cls = [&](int32_t k) {
-            if (!bin[k].is_leaf) return 0;
-            return ((uint32_t)(-1 - bin[k].leaf_ref) & kLeafCodeOther) ? 2 : 1;
-        };
-        std::stable_sort(kids, kids + nk, [&](int32_t a, int32_t b) { return cls(a) < cls(b); });
-        int ni = 0, nt = 0;
-        for (int k = 0; k < nk; k++) {
-            ni += cls(kids[k]) == 0;
-            nt += cls(kids[k]) <= 1;
-        }
-        const uint32_t child_base = (uint32_t)nodes.size();
-        nodes.resize(nodes.size() + (size_t)ni);
-        const uint32_t leaf_base = (uint32_t)order.size();
-        for (int k = ni; k < nk; k++) {
-            const uint32_t code = (uint32_t)(-1 - bin[kids[k]].leaf_ref);
-            order.push_back(order_in[(code & ~kLeafCodeOther) >> 3]);  // one primitive per leaf (build_bvh8 forces it)
-        }
-        DevNode8 nd;
-        std::memset(&nd, 0, sizeof(nd));
-        Box kb[8];
-        for (int k = 0; k < nk; k++) kb[k] = bin[kids[k]].box;
-        uint8_t* ebits[3] = {&nd.ex, &nd.ey, &nd.ez};
-        float* org[3] = {&nd.ox, &nd.oy, &nd.oz};
-        for (int a = 0; a < 3; a++) {
-            for (int k = 0; k < 8; k++) {
-                nd.q[a][k] = 255;      // unused slots: an inverted box
-                nd.q[3 + a][k] = 0;
-            }
-            quantise_axis(kb, nk, a, *org[a], *ebits[a], nd.q[a], nd.q[3 + a]);
-        }
-        for (int k = 0; k < nk; k++) {  // diagnostic: how much the 8-bit grid inflates the boxes
-            Box qb;
-            for (int a = 0; a < 3; a++) {
-                const double cell = std::ldexp(1.0, (int)*ebits[a] - 127);
-                qb.mn[a] = (double)*org[a] + nd.q[a][k] * cell;
-                qb.mx[a] = (double)*org[a] + nd.q[3 + a][k] * cell;
-            }
-            area_q += qb.half_area();
-            area_x += kb[k].half_area();
-        }
-        nd.ni = nd.ni2 = (uint8_t)ni;
-        nd.nt = (uint8_t)nt;
-        nd.nv = (uint8_t)nk;
-        nd.child_base = child_base;
-        nd.leaf_base = leaf_base;
-        nodes[me] = nd;
-        uint32_t below = 0;
-        for (int k = 0; k < ni; k++) below = std::max(below, emit(kids[k], child_base + (uint32_t)k, depth + 1));
-        return (uint32_t)(nk - 1) + below;
-    }
-};
-}  // namespace
-
-void build_bvh8(const rt_primitive* prims, size_t n, Bvh8Out& out, int width) {
-    out = Bvh8Out{};
-    if (n == 0) return;
-    for (uint32_t cap : {64u, 16u, 8u, 0u}) {
-        Builder bd(prims, n);
-        bd.max_leaf = 1;  // a child reference is computed from the slot number: one primitive per leaf
-        bd.sah_depth = std::min(bd.sah_depth, cap);
-        const int32_t root = build_binary(bd, n);
-        out.nodes.clear();
-        out.order.clear();
-        out.nodes.reserve(bd.bin.size() / 4 + 2);
-        out.order.reserve(n);
-        Collapser8 col(bd.bin, bd.order, prims, out.nodes, out.order);
-        col.width = width;
-        out.nodes.resize(1);
-        if (bd.bin[root].is_leaf) {  // a single primitive: node 0 is always internal
-            DevNode8 nd;
-            std::memset(&nd, 0, sizeof(nd));
-            Box kb[1] = {bd.bin[root].box};
-            uint8_t* ebits[3] = {&nd.ex, &nd.ey, &nd.ez};
-            float* org[3] = {&nd.ox, &nd.oy, &nd.oz};
-            for (int a = 0; a < 3; a++) {
-                for (int k = 0; k < 8; k++) {
-                    nd.q[a][k] = 255;
-                    nd.q[3 + a][k] = 0;
-                }
-                Collapser8::quantise_axis(kb, 1, a, *org[a], *ebits[a], nd.q[a], nd.q[3 + a]);
-            }
-            const bool other = ((uint32_t)(-1 - bd.bin[root].leaf_ref) & kLeafCodeOther) != 0;
-            nd.ni = nd.ni2 = 0;
-            nd.nt = other ? 0 : 1;
-            nd.nv = 1;
-            out.order.push_back(bd.order[0]);
-            out.nodes[0] = nd;
-            out.depth = 0;
-            out.stack_need = 0;
-            out.quant_area_ratio = 1.0;
-            return;
-        }
-        out.stack_need = col.emit(root, 0, 0);
-        out.depth = col.max_depth;
-        out.quant_area_ratio = col.area_x > 0.0 ? col.area_q / col.area_x : 1.0;
-        if (out.stack_need + 2 <= 12u + 98u) return;  // geom.h: kLdsStack + the private overflow of the RT_BVH8 build
-    }
-}
-
 void build_sah_binary(const double* boxes, size_t n, std::vector<int32_t>& left, std::vector<int32_t>& right) {
     left.assign(n > 1 ? n - 1 : 0, 0);
     right.assign(n > 1 ? n - 1 : 0, 0);

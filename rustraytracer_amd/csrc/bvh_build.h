@@ -16,18 +16,6 @@ struct BvhOut {
 
 void build_bvh(const rt_primitive* prims, size_t n, BvhOut& out);
 
-// experiment RT_BVH8: the same binned-SAH binary tree collapsed to 8 children per node, boxes quantised on the
-// node's grid (scene_dev.h: DevNode8).  One primitive per leaf.  stack_need = the deepest the traversal's stack can get
-// (7 pending siblings per level).
-struct Bvh8Out {
-    std::vector<DevNode8> nodes;
-    std::vector<uint32_t> order;  // leaf order -> primitive index (a node's leaf children are consecutive)
-    uint32_t depth = 0;
-    uint32_t stack_need = 0;
-    double quant_area_ratio = 0.0;  // diagnostic: sum of decoded child areas / sum of exact child areas
-};
-void build_bvh8(const rt_primitive* prims, size_t n, Bvh8Out& out, int width = 8);  // width 4: RT_BVH8 = 2 (64-B nodes)
-
 // Binned-SAH BINARY tree over n boxes (6 doubles each: min xyz, max xyz), one box per leaf -- the top of the device
 // builder's tree (bvh_gpu.hip: clusters of the Morton-order tree become the leaves).  Internal nodes are numbered
 // 0 .. n-2 with the root at 0; a child reference >= 0 is an internal node, < 0 is ~(box index).  n >= 2.

@@ -481,17 +481,8 @@ struct TravCount {
 #ifndef RT_TRACE_WAVES
 #define RT_TRACE_WAVES 5
 #endif
-#ifndef RT_BVH8
-#define RT_BVH8 0  // (experiment, round 3) 1: the 8-wide tree with 8-bit child boxes (scene_dev.h: DevNode8) replaces the BVH4;
-                   // 2: the 4-wide tree with 8-bit boxes in 64-B records (build with -DRT_LDS_NODES=0).  Both measured slower:
-                   // profiles/r03_exp_bvh8_q8*.txt, r03_exp_q4_nodes.txt
-#endif
 constexpr int kLdsStack = RT_LDS_STACK;
-#if RT_BVH8
-constexpr int kOvfStack = 98;  // an 8-wide node pushes up to seven children; bvh_build.cpp bounds the need by 16 + 98
-#else
 constexpr int kOvfStack = 3 * kMaxBvhDepth + 2 - kLdsStack;  // a 4-wide node pushes up to three children
-#endif
 // BVH-node tiles staged in LDS (BASELINE north_star): every block of k_trace copies the first RT_LDS_NODES nodes -- the
 // top of the tree, which rt_scene_commit lays out breadth-first (levels 0-2 are 21 nodes) and which every ray walks --
 // into LDS once; node_step reads them with ds_read and everything else with global loads.  Round 2 measured a version
@@ -660,7 +651,6 @@ RTD void trav_pop(Trav& tv, TravStack& ts) {
 
 // One internal node: test its four children (one 128-B fetch), descend into the nearest hit and push
 // the others so that they pop nearest-first.
-#if !RT_BVH8
 template <bool COUNT>
 RTD void node_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
     // near / far plane rows of the node picked by the direction signs (rows: lo_x lo_y lo_z hi_x hi_y hi_z,
@@ -745,199 +735,6 @@ RTD void node_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
     if (nh > 1) { stack_push(ts, tv.sp, c1, d1); tv.sp++; }
     tv.cur = c0;
 }
-#endif  // !RT_BVH8
-
-#if RT_BVH8 == 2
-// ---- experiment RT_BVH8 = 2: the 4-wide tree with 8-bit child boxes in a 64-B record, FOUR 16-B loads per visit instead
-// of seven and half the bytes (abi.hip packs build_bvh8(width 4)'s nodes):
-//   [ 0,16) grid origin x y z (f32), {ex, ey, ez, nv}      [16,32) child_base, leaf_base, {ni, nt, 0, 0}, lo_x[4]
-//   [32,48) lo_y[4] lo_z[4] hi_x[4] hi_y[4]                [48,52) hi_z[4]
-// Arithmetic, slack and child references as in the 8-wide node below; the key carries the slot in its low TWO bits.
-template <bool COUNT>
-RTD void node_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
-    const char* nb = reinterpret_cast<const char*>(sc.nodes) + (size_t)(uint32_t)tv.cur * 64u;
-    const uint4 h0 = *reinterpret_cast<const uint4*>(nb);
-    const uint4 h1 = *reinterpret_cast<const uint4*>(nb + 16u);
-    const uint4 qa = *reinterpret_cast<const uint4*>(nb + 32u);  // lo_y lo_z hi_x hi_y
-    const uint32_t qhz = *reinterpret_cast<const uint32_t*>(nb + 48u);
-    if (COUNT) tc->nodes++;
-    const float tmin32 = float_lower(tv.tmin);
-    const float tmax32 = (float)tv.tmax * (1.0f + kNodeSlack);
-    const float lim32 = __builtin_fminf((float)prune_limit(tv) * (1.0f + kNodeSlack), tmax32);
-    const float ox = __uint_as_float(h0.x), oy = __uint_as_float(h0.y), oz = __uint_as_float(h0.z);
-    const float cx = __uint_as_float((h0.w & 0xffu) << 23), cy = __uint_as_float(((h0.w >> 8) & 0xffu) << 23),
-                cz = __uint_as_float(((h0.w >> 16) & 0xffu) << 23);
-    const uint32_t nv = h0.w >> 24;
-    const float sx = cx * tv.ix, sy = cy * tv.iy, sz = cz * tv.iz;
-    float bnx = __builtin_fmaf(ox, tv.ix, tv.cnx), bny = __builtin_fmaf(oy, tv.iy, tv.cny), bnz = __builtin_fmaf(oz, tv.iz, tv.cnz);
-    float bfx = __builtin_fmaf(ox, tv.ix, tv.cfx), bfy = __builtin_fmaf(oy, tv.iy, tv.cfy), bfz = __builtin_fmaf(oz, tv.iz, tv.cfz);
-    bnx = __builtin_fmaf(-__builtin_fabsf(bnx), kNodeSlack, bnx);
-    bny = __builtin_fmaf(-__builtin_fabsf(bny), kNodeSlack, bny);
-    bnz = __builtin_fmaf(-__builtin_fabsf(bnz), kNodeSlack, bnz);
-    bfx = __builtin_fmaf(__builtin_fabsf(bfx), kNodeSlack, bfx);
-    bfy = __builtin_fmaf(__builtin_fabsf(bfy), kNodeSlack, bfy);
-    bfz = __builtin_fmaf(__builtin_fabsf(bfz), kNodeSlack, bfz);
-    const bool ngx = (__float_as_uint(tv.ix) >> 31) != 0u, ngy = (__float_as_uint(tv.iy) >> 31) != 0u,
-               ngz = (__float_as_uint(tv.iz) >> 31) != 0u;
-    const uint32_t lox = h1.w, loy = qa.x, loz = qa.y, hix = qa.z, hiy = qa.w, hiz = qhz;
-    const uint32_t nx = ngx ? hix : lox, fx = ngx ? lox : hix;
-    const uint32_t ny = ngy ? hiy : loy, fy = ngy ? loy : hiy;
-    const uint32_t nz = ngz ? hiz : loz, fz = ngz ? loz : hiz;
-    const uint32_t ni = h1.z & 0xffu, nt = (h1.z >> 8) & 0xffu;
-#define RT_Q(w, k) ((float)(((w) >> (8 * (k))) & 0xffu))
-#define RT_NODE4Q_CHILD(k, key)                                                                            \
-    uint32_t key;                                                                                          \
-    {                                                                                                      \
-        const float m_ = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(RT_Q(nx, k), sx, bnx),             \
-                                                         __builtin_fmaf(RT_Q(ny, k), sy, bny)),            \
-                                         __builtin_fmaf(RT_Q(nz, k), sz, bnz));                            \
-        const float f_ = __builtin_fminf(__builtin_fminf(__builtin_fmaf(RT_Q(fx, k), sx, bfx),             \
-                                                         __builtin_fmaf(RT_Q(fy, k), sy, bfy)),            \
-                                         __builtin_fmaf(RT_Q(fz, k), sz, bfz));                            \
-        const float e_ = __builtin_fmaxf(__builtin_fmaf(-__builtin_fabsf(m_), kNodeSlack, m_), tmin32);     \
-        const float x_ = __builtin_fminf(__builtin_fmaf(__builtin_fabsf(f_), kNodeSlack, f_), lim32);      \
-        key = (e_ <= x_ && (uint32_t)(k) < nv) ? ((__float_as_uint(e_) & 0x7ffffffcu) | (uint32_t)(k)) : 0xffffffffu; \
-    }
-    RT_NODE4Q_CHILD(0, k0)
-    RT_NODE4Q_CHILD(1, k1)
-    RT_NODE4Q_CHILD(2, k2)
-    RT_NODE4Q_CHILD(3, k3)
-#undef RT_NODE4Q_CHILD
-#undef RT_Q
-#define RT_KSWAP(a, b)                                \
-    {                                                 \
-        const uint32_t lo_ = a < b ? a : b;           \
-        b = a < b ? b : a;                            \
-        a = lo_;                                      \
-    }
-    RT_KSWAP(k0, k1) RT_KSWAP(k2, k3) RT_KSWAP(k0, k2) RT_KSWAP(k1, k3) RT_KSWAP(k1, k2)
-#undef RT_KSWAP
-    if (k0 == 0xffffffffu) {
-        trav_pop(tv, ts);
-        return;
-    }
-    const uint32_t cbase = h1.x, lbase = h1.y - ni;  // leaf slot of child `slot` = lbase + slot
-    auto child_ref = [&](uint32_t key) -> int32_t {
-        const uint32_t slot = key & 3u;
-        const uint32_t leaf = ((lbase + slot) << 3) | (slot >= nt ? kLeafCodeOther : 0u);
-        return slot < ni ? (int32_t)(cbase + slot) : -1 - (int32_t)leaf;
-    };
-    // farthest first, so that the nearest pending child is on top of the stack
-    if (k3 != 0xffffffffu) { stack_push(ts, tv.sp, child_ref(k3), __uint_as_float(k3 & 0x7ffffffcu)); tv.sp++; }
-    if (k2 != 0xffffffffu) { stack_push(ts, tv.sp, child_ref(k2), __uint_as_float(k2 & 0x7ffffffcu)); tv.sp++; }
-    if (k1 != 0xffffffffu) { stack_push(ts, tv.sp, child_ref(k1), __uint_as_float(k1 & 0x7ffffffcu)); tv.sp++; }
-    tv.cur = child_ref(k0);
-}
-#elif RT_BVH8
-// ---- experiment RT_BVH8: one 8-wide node with 8-bit child boxes (scene_dev.h: DevNode8), five 16-B loads.
-// plane = origin + q * 2^e, so the ray parameter of a plane is
-//     t = (plane - o) / d = q * (2^e * inv) + (origin - o) * inv  ~  fma(q, s, b),   s = 2^e * inv32 (exact scaling),
-//     b = fma(origin, inv32, c),  c = the per-ray constant of node_step (-(o * inv32) -/+ its rounding slack).
-// Error against the f64 value, beyond what node_step's analysis covers (inv32 vs 1/d, the rounding of c, the single
-// rounding of the last fma -- all relative to |t| or folded into c): the rounding of b, 2^-24 |b|, where |b| -- the
-// parameter of the node's origin plane -- can be far larger than |t| for a ray that starts inside the node.  It is
-// folded into b as an absolute slack of 2^-21 |b| (lower for the near planes, higher for the far planes).  The 8-bit
-// planes themselves are conservative by construction (bvh_build.cpp: lower planes rounded down, upper planes up).
-// Children: slots [0, ni) nodes child_base + slot, [ni, nt) triangle leaves, [nt, nv) sphere / rect leaves at leaf slot
-// leaf_base + slot - ni.  Hit children are ordered by a 32-bit key = entry parameter (>= 0, so its bit pattern orders
-// like the value) with the low three mantissa bits replaced by the slot number: an 8-key sorting network of
-// v_min_u32 / v_max_u32 pairs, no payload to carry.  The entry parameter that goes on the stack is the key with
-// those bits cleared, i.e. rounded DOWN by at most 2^-20 relative: pop-time pruning only gets more conservative.
-template <bool COUNT>
-RTD void node_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
-    const char* nb = reinterpret_cast<const char*>(sc.nodes) + (size_t)(uint32_t)tv.cur * 128u;
-    const uint4 h0 = *reinterpret_cast<const uint4*>(nb);
-    const uint4 h1 = *reinterpret_cast<const uint4*>(nb + 16u);
-    const uint4 qa = *reinterpret_cast<const uint4*>(nb + 32u);  // lo_x[8] lo_y[8]
-    const uint4 qb = *reinterpret_cast<const uint4*>(nb + 48u);  // lo_z[8] hi_x[8]
-    const uint4 qc = *reinterpret_cast<const uint4*>(nb + 64u);  // hi_y[8] hi_z[8]
-    if (COUNT) tc->nodes++;
-    const float tmin32 = float_lower(tv.tmin);
-    const float tmax32 = (float)tv.tmax * (1.0f + kNodeSlack);
-    const float lim32 = __builtin_fminf((float)prune_limit(tv) * (1.0f + kNodeSlack), tmax32);
-    const float ox = __uint_as_float(h0.x), oy = __uint_as_float(h0.y), oz = __uint_as_float(h0.z);
-    // cell sizes as floats: the stored byte IS the exponent field
-    const float cx = __uint_as_float((h0.w & 0xffu) << 23), cy = __uint_as_float(((h0.w >> 8) & 0xffu) << 23),
-                cz = __uint_as_float(((h0.w >> 16) & 0xffu) << 23);
-    const float sx = cx * tv.ix, sy = cy * tv.iy, sz = cz * tv.iz;
-    float bnx = __builtin_fmaf(ox, tv.ix, tv.cnx), bny = __builtin_fmaf(oy, tv.iy, tv.cny), bnz = __builtin_fmaf(oz, tv.iz, tv.cnz);
-    float bfx = __builtin_fmaf(ox, tv.ix, tv.cfx), bfy = __builtin_fmaf(oy, tv.iy, tv.cfy), bfz = __builtin_fmaf(oz, tv.iz, tv.cfz);
-    bnx = __builtin_fmaf(-__builtin_fabsf(bnx), kNodeSlack, bnx);
-    bny = __builtin_fmaf(-__builtin_fabsf(bny), kNodeSlack, bny);
-    bnz = __builtin_fmaf(-__builtin_fabsf(bnz), kNodeSlack, bnz);
-    bfx = __builtin_fmaf(__builtin_fabsf(bfx), kNodeSlack, bfx);
-    bfy = __builtin_fmaf(__builtin_fabsf(bfy), kNodeSlack, bfy);
-    bfz = __builtin_fmaf(__builtin_fabsf(bfz), kNodeSlack, bfz);
-    // near / far rows by the direction signs (two dwords = eight slots each)
-    const bool ngx = (__float_as_uint(tv.ix) >> 31) != 0u, ngy = (__float_as_uint(tv.iy) >> 31) != 0u,
-               ngz = (__float_as_uint(tv.iz) >> 31) != 0u;
-    const uint32_t nx0 = ngx ? qb.z : qa.x, nx1 = ngx ? qb.w : qa.y, fx0 = ngx ? qa.x : qb.z, fx1 = ngx ? qa.y : qb.w;
-    const uint32_t ny0 = ngy ? qc.x : qa.z, ny1 = ngy ? qc.y : qa.w, fy0 = ngy ? qa.z : qc.x, fy1 = ngy ? qa.w : qc.y;
-    const uint32_t nz0 = ngz ? qc.z : qb.x, nz1 = ngz ? qc.w : qb.y, fz0 = ngz ? qb.x : qc.z, fz1 = ngz ? qb.y : qc.w;
-    const uint32_t ni = h1.z & 0xffu, nt = (h1.z >> 8) & 0xffu, nv = (h1.z >> 16) & 0xffu;
-#define RT_Q(w, k) ((float)(((w) >> (8 * (k))) & 0xffu))
-#define RT_NODE8_CHILD(c, NX, NY, NZ, FX, FY, FZ, k, key)                                                  \
-    uint32_t key;                                                                                          \
-    {                                                                                                      \
-        const float m_ = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(RT_Q(NX, k), sx, bnx),             \
-                                                         __builtin_fmaf(RT_Q(NY, k), sy, bny)),            \
-                                         __builtin_fmaf(RT_Q(NZ, k), sz, bnz));                            \
-        const float f_ = __builtin_fminf(__builtin_fminf(__builtin_fmaf(RT_Q(FX, k), sx, bfx),             \
-                                                         __builtin_fmaf(RT_Q(FY, k), sy, bfy)),            \
-                                         __builtin_fmaf(RT_Q(FZ, k), sz, bfz));                            \
-        const float e_ = __builtin_fmaxf(__builtin_fmaf(-__builtin_fabsf(m_), kNodeSlack, m_), tmin32);     \
-        const float x_ = __builtin_fminf(__builtin_fmaf(__builtin_fabsf(f_), kNodeSlack, f_), lim32);      \
-        key = (e_ <= x_ && (uint32_t)(c) < nv) ? ((__float_as_uint(e_) & 0x7ffffff8u) | (uint32_t)(c)) : 0xffffffffu; \
-    }
-    RT_NODE8_CHILD(0, nx0, ny0, nz0, fx0, fy0, fz0, 0, k0)
-    RT_NODE8_CHILD(1, nx0, ny0, nz0, fx0, fy0, fz0, 1, k1)
-    RT_NODE8_CHILD(2, nx0, ny0, nz0, fx0, fy0, fz0, 2, k2)
-    RT_NODE8_CHILD(3, nx0, ny0, nz0, fx0, fy0, fz0, 3, k3)
-    RT_NODE8_CHILD(4, nx1, ny1, nz1, fx1, fy1, fz1, 0, k4)
-    RT_NODE8_CHILD(5, nx1, ny1, nz1, fx1, fy1, fz1, 1, k5)
-    RT_NODE8_CHILD(6, nx1, ny1, nz1, fx1, fy1, fz1, 2, k6)
-    RT_NODE8_CHILD(7, nx1, ny1, nz1, fx1, fy1, fz1, 3, k7)
-#undef RT_NODE8_CHILD
-#undef RT_Q
-    // 19-comparator sorting network for 8 keys (misses = 0xffffffff sink to the end)
-#define RT_KSWAP(a, b)                                \
-    {                                                 \
-        const uint32_t lo_ = a < b ? a : b;           \
-        b = a < b ? b : a;                            \
-        a = lo_;                                      \
-    }
-    RT_KSWAP(k0, k1) RT_KSWAP(k2, k3) RT_KSWAP(k4, k5) RT_KSWAP(k6, k7)
-    RT_KSWAP(k0, k2) RT_KSWAP(k1, k3) RT_KSWAP(k4, k6) RT_KSWAP(k5, k7)
-    RT_KSWAP(k1, k2) RT_KSWAP(k5, k6) RT_KSWAP(k0, k4) RT_KSWAP(k3, k7)
-    RT_KSWAP(k1, k5) RT_KSWAP(k2, k6)
-    RT_KSWAP(k1, k4) RT_KSWAP(k3, k6)
-    RT_KSWAP(k2, k4) RT_KSWAP(k3, k5)
-    RT_KSWAP(k3, k4)
-#undef RT_KSWAP
-    if (k0 == 0xffffffffu) {
-        trav_pop(tv, ts);
-        return;
-    }
-    const uint32_t cbase = h1.x, lbase = h1.y - ni;  // leaf slot of child `slot` = lbase + slot
-    auto child_ref = [&](uint32_t key) -> int32_t {
-        const uint32_t slot = key & 7u;
-        const uint32_t leaf = ((lbase + slot) << 3) | (slot >= nt ? kLeafCodeOther : 0u);
-        return slot < ni ? (int32_t)(cbase + slot) : -1 - (int32_t)leaf;
-    };
-    // farthest first, so that the nearest pending child is on top of the stack; a wave-uniform test skips the pushes
-    // no lane needs (most nodes have two or three hit children)
-#define RT_PUSH8(key)                                                                  \
-    if (__ballot(key != 0xffffffffu) != 0ull) {                                        \
-        if (key != 0xffffffffu) {                                                      \
-            stack_push(ts, tv.sp, child_ref(key), __uint_as_float(key & 0x7ffffff8u)); \
-            tv.sp++;                                                                   \
-        }                                                                              \
-    }
-    RT_PUSH8(k7) RT_PUSH8(k6) RT_PUSH8(k5) RT_PUSH8(k4) RT_PUSH8(k3) RT_PUSH8(k2) RT_PUSH8(k1)
-#undef RT_PUSH8
-    tv.cur = child_ref(k0);
-}
-#endif  // RT_BVH8
 
 // One primitive of the current leaf (leaf code: -1 - ((first*8 + count-1) | kLeafCodeOther?)); pops after
 // the last one.  Ties in t go to the larger prim index (ABI tie rule).

@@ -35,29 +35,6 @@ constexpr int kMaxLeafPrims = 4;     // what a leaf code can hold
 constexpr int kLeafTargetPrims = 1;
 constexpr int kMaxBvhDepth = 24;  // of the 4-wide tree; traversal stack: 16 LDS + 58 private entries (geom.h)
 
-// ---- experiment RT_BVH8 (round 3): an 8-wide node with the children's boxes quantised to 8 bits
-// on the node's own grid, 80 B of one 128-B line, fetched with FIVE 16-B loads (the BVH4 node above takes seven):
-//   [ 0,16)  grid origin (f32, rounded down: <= every child's lower corner), then the three cell-size exponents
-//            (biased like an f32 exponent: cell = 2^(e - 127)) and ni
-//   [16,32)  child_base, leaf_base, {ni, nt, nv, 0} again as bytes, pad
-//   [32,80)  q[6][8]: lo_x lo_y lo_z hi_x hi_y hi_z of the eight slots, plane = origin + q * cell, lower planes
-//            rounded down and upper planes rounded up, so the decoded box contains the child's f64 box
-// Children are ordered by kind, which makes a child reference arithmetic instead of a 32-B table:
-//   slots [0, ni)   internal nodes   child_base + slot            (a node's internal children are consecutive)
-//   slots [ni, nt)  triangle leaves  leaf slot leaf_base + slot - ni   (one primitive per leaf, consecutive leaf slots)
-//   slots [nt, nv)  sphere / rect leaves, likewise, flagged kLeafCodeOther
-// The f64 gate of a primitive stays the leaf's own box (geom.h), so films cannot change; only culling does.
-struct DevNode8 {
-    float ox, oy, oz;
-    uint8_t ex, ey, ez, ni;
-    uint32_t child_base, leaf_base;
-    uint8_t ni2, nt, nv, pad8;
-    uint32_t pad0;
-    uint8_t q[6][8];
-    uint32_t pad[12];
-};
-static_assert(sizeof(DevNode8) == 128, "DevNode8 must be 128 bytes");
-
 // rt_material with its texture references resolved at commit: a solid-colour texture (the usual case) is
 // embedded, so compute_scattering reads material -> colour in one fetch instead of material -> texture record.
 struct DevMat {

@@ -312,177 +312,6 @@ static int trace_wide(const Scene& s, const Wide& w, V o, V dir, double tmax, Co
     }
 }
 
-// ---- the RT_BVH8 experiment's own tree (rtd::build_bvh8: DevNode8, 8-bit boxes on the node's grid)
-struct Scene8 {
-    const rt_scene_desc* d;
-    Bvh8Out bvh;
-    std::vector<double> xlo, xhi;  // exact child boxes [node * 8 + k][3] (validate8), for the Q8_EXACTBOX comparison
-};
-static void decode8(const DevNode8& nd, int k, double* lo, double* hi) {
-    const double org[3] = {nd.ox, nd.oy, nd.oz};
-    const int e[3] = {nd.ex - 127, nd.ey - 127, nd.ez - 127};
-    for (int a = 0; a < 3; a++) {
-        lo[a] = org[a] + nd.q[a][k] * std::ldexp(1.0, e[a]);
-        hi[a] = org[a] + nd.q[3 + a][k] * std::ldexp(1.0, e[a]);
-    }
-}
-// every primitive exactly once, and every decoded child box contains the exact box of what hangs below it
-static bool validate8(Scene8& s) {
-    s.xlo.assign(s.bvh.nodes.size() * 24, 0.0);
-    s.xhi.assign(s.bvh.nodes.size() * 24, 0.0);
-    const size_t np = s.d->n_prims;
-    std::vector<int> seen(np, 0);
-    for (uint32_t id : s.bvh.order) {
-        if (id >= np) return false;
-        seen[id]++;
-    }
-    for (size_t i = 0; i < np; i++)
-        if (seen[i] != 1) return false;
-    struct B {
-        double lo[3], hi[3];
-    };
-    std::vector<B> exact(s.bvh.nodes.size());
-    std::vector<char> visited(s.bvh.nodes.size(), 0);
-    unsigned long long loose = 0, checked = 0;
-    // post-order by recursion (depth is small)
-    struct Rec {
-        Scene8& s;
-        std::vector<B>& exact;
-        std::vector<char>& visited;
-        unsigned long long &loose, &checked;
-        bool ok = true;
-        void go(uint32_t ni) {
-            if (ni >= s.bvh.nodes.size() || visited[ni]) {
-                ok = false;
-                return;
-            }
-            visited[ni] = 1;
-            const DevNode8& nd = s.bvh.nodes[ni];
-            B me;
-            for (int a = 0; a < 3; a++) {
-                me.lo[a] = INFINITY;
-                me.hi[a] = -INFINITY;
-            }
-            if (nd.ni != nd.ni2 || nd.ni > nd.nt || nd.nt > nd.nv || nd.nv > 8 || nd.nv == 0) ok = false;
-            for (int k = 0; k < nd.nv && ok; k++) {
-                B cb;
-                if (k < nd.ni) {
-                    go(nd.child_base + k);
-                    if (!ok) return;
-                    cb = exact[nd.child_base + k];
-                } else {
-                    const uint32_t slot = nd.leaf_base + (k - nd.ni);
-                    if (slot >= s.bvh.order.size()) {
-                        ok = false;
-                        return;
-                    }
-                    const rt_primitive& p = s.d->prims[s.bvh.order[slot]];
-                    if ((p.kind != RT_PRIM_TRIANGLE) != (k >= nd.nt)) ok = false;
-                    for (int a = 0; a < 3; a++) {
-                        cb.lo[a] = p.bbox_min[a];
-                        cb.hi[a] = p.bbox_max[a];
-                    }
-                }
-                double lo[3], hi[3];
-                decode8(nd, k, lo, hi);
-                for (int a = 0; a < 3; a++) {
-                    s.xlo[((size_t)ni * 8 + k) * 3 + a] = cb.lo[a];
-                    s.xhi[((size_t)ni * 8 + k) * 3 + a] = cb.hi[a];
-                    checked++;
-                    if (!(lo[a] <= cb.lo[a] && hi[a] >= cb.hi[a])) {
-                        loose++;
-                        ok = false;
-                    }
-                    me.lo[a] = std::min(me.lo[a], cb.lo[a]);
-                    me.hi[a] = std::max(me.hi[a], cb.hi[a]);
-                }
-            }
-            exact[ni] = me;
-        }
-    } rec{s, exact, visited, loose, checked};
-    rec.go(0);
-    for (char v : visited)
-        if (!v) rec.ok = false;
-    std::printf("bvh8 validate: %s (%llu planes checked, %llu not conservative)\n", rec.ok ? "ok" : "FAILED", checked, loose);
-    return rec.ok;
-}
-static int trace8(const Scene8& s, V o, V dir, double tmax, Count& c, bool exact_order) {
-    const double inv[3] = {1.0 / dir.x, 1.0 / dir.y, 1.0 / dir.z}, oo[3] = {o.x, o.y, o.z};
-    struct E {
-        int32_t node;
-        double t;
-    };
-    E stack[512];
-    int sp = 0;
-    int32_t cur = 0;
-    int best = -1;
-    double best_t = tmax;
-    c.rays++;
-    for (;;) {
-        if (cur >= 0) {
-            const DevNode8& nd = s.bvh.nodes[cur];
-            c.nodes++;
-            E hit[8];
-            int nh = 0;
-            for (int k = 0; k < nd.nv; k++) {
-                double lo[3], hi[3];
-                decode8(nd, k, lo, hi);
-                static const bool xbox = getenv("Q8_EXACTBOX") != nullptr;
-                if (xbox)
-                    for (int a = 0; a < 3; a++) {
-                        lo[a] = s.xlo[((size_t)cur * 8 + k) * 3 + a];
-                        hi[a] = s.xhi[((size_t)cur * 8 + k) * 3 + a];
-                    }
-                double tn = 1e-3, tf = best_t;
-                for (int a = 0; a < 3; a++) {
-                    double t0 = (lo[a] - oo[a]) * inv[a], t1 = (hi[a] - oo[a]) * inv[a];
-                    if (t0 > t1) std::swap(t0, t1);
-                    if (t0 > tn) tn = t0;
-                    if (t1 < tf) tf = t1;
-                }
-                if (!(tf <= tn)) {
-                    const int32_t ref = k < nd.ni ? (int32_t)(nd.child_base + k) : -1 - (int32_t)(nd.leaf_base + (k - nd.ni));
-                    if (!exact_order) {  // the kernel's key: entry distance as f32 with the low three bits replaced by the slot
-                        float f = (float)tn;
-                        uint32_t b;
-                        std::memcpy(&b, &f, 4);
-                        b = (b & 0x7ffffff8u) | (uint32_t)k;
-                        hit[nh++] = E{ref, (double)b};
-                    } else
-                        hit[nh++] = E{ref, tn};
-                }
-            }
-            std::sort(hit, hit + nh, [](const E& a, const E& b) { return a.t > b.t; });
-            for (int k = 0; k < nh; k++) {
-                if (!exact_order) {
-                    uint32_t b = (uint32_t)hit[k].t & ~7u;
-                    float f;
-                    std::memcpy(&f, &b, 4);
-                    hit[k].t = f;
-                }
-                stack[sp++] = hit[k];
-            }
-        } else {
-            c.prims++;
-            double t;
-            V n;
-            const uint32_t pi = s.bvh.order[(uint32_t)(-1 - cur)];
-            if (hit_prim(Scene{s.d, {}}, pi, o, dir, best_t, t, n) && t < best_t) {
-                best_t = t;
-                best = (int)pi;
-            }
-        }
-        for (;;) {
-            if (sp == 0) return best;
-            const E e = stack[--sp];
-            if (e.t <= best_t) {
-                cur = e.node;
-                break;
-            }
-        }
-    }
-}
-
 static unsigned long long rng_state = 88172645463325252ull;
 static double rnd() {
     rng_state ^= rng_state << 13;
@@ -526,16 +355,7 @@ int main(int argc, char** argv) {
     widen(s.bvh, 0, w8);
     widen(s.bvh, 0, w16);
     std::printf("re-collapsed: %zu nodes of up to 8 children, %zu of up to 16\n", w8.nodes.size(), w16.nodes.size());
-    Count c8, c16, q8;
-    Scene8 s8;
-    s8.d = s.d;
-    const auto t8 = std::chrono::steady_clock::now();
-    build_bvh8(s.d->prims, s.d->n_prims, s8.bvh);
-    std::printf("bvh8 (quantised, RT_BVH8): %zu nodes, depth %u, stack need %u, decoded/exact child area %.4f, build %.2f s\n",
-                s8.bvh.nodes.size(), s8.bvh.depth, s8.bvh.stack_need, s8.bvh.quant_area_ratio,
-                std::chrono::duration<double>(std::chrono::steady_clock::now() - t8).count());
-    if (!validate8(s8)) return 2;
-    unsigned long long mismatch8 = 0;
+    Count c8, c16;
     const V org{cam.origin[0], cam.origin[1], cam.origin[2]}, ulc{cam.upper_left_corner[0], cam.upper_left_corner[1], cam.upper_left_corner[2]};
     const V ho{cam.horizontal_offset[0], cam.horizontal_offset[1], cam.horizontal_offset[2]};
     const V vo{cam.vertical_offset[0], cam.vertical_offset[1], cam.vertical_offset[2]};
@@ -544,7 +364,6 @@ int main(int argc, char** argv) {
         double t;
         V n;
         int hit = trace(s, org, dir, 1e308, t, n, cp);
-        mismatch8 += trace8(s8, org, dir, 1e308, q8, getenv("Q8_EXACT") != nullptr) != hit;
         trace_wide(s, w8, org, dir, 1e308, c8);
         trace_wide(s, w16, org, dir, 1e308, c16);
         V p = org + dir * t, wo = dir;
@@ -554,7 +373,6 @@ int main(int argc, char** argv) {
             double ts;
             V ns;
             const int hs_ = trace(s, p, light_c - p, 1e308, ts, ns, cs);
-            mismatch8 += trace8(s8, p, light_c - p, 1e308, q8, getenv("Q8_EXACT") != nullptr) != hs_;
             trace_wide(s, w8, p, light_c - p, 1e308, c8);
             trace_wide(s, w16, p, light_c - p, 1e308, c16);
             const double r1 = rnd(), r2 = rnd(), ph = 6.283185307179586 * r1, sr = std::sqrt(r2);
@@ -562,7 +380,6 @@ int main(int argc, char** argv) {
             const V d2 = tn * (std::cos(ph) * sr) + bn * (std::sin(ph) * sr) + n * std::sqrt(1.0 - r2);
             Count& cc = bounce == 0 ? cb : cb2;
             hit = trace(s, p, d2, 1e308, t, n, cc);
-            mismatch8 += trace8(s8, p, d2, 1e308, q8, getenv("Q8_EXACT") != nullptr) != hit;
             trace_wide(s, w8, p, d2, 1e308, c8);
             trace_wide(s, w16, p, d2, 1e308, c16);
             p = p + d2 * t;
@@ -586,8 +403,6 @@ int main(int argc, char** argv) {
     pr("all", all);
     pr("all, 8-wide", c8);
     pr("all, 16-wide", c16);
-    pr("all, bvh8 q8", q8);
-    std::printf("bvh8 q8: %llu of %llu rays found another primitive than the BVH4 walk (ties aside, must be 0)\n", mismatch8, q8.rays);
     rrh_scene_destroy(hs);
     return 0;
 }
