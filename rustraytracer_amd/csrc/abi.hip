@@ -23,10 +23,17 @@
 #include "bvh_build.h"
 #include "bvh_gpu.h"
 #include "env_dist.h"
-#include "device/kernels.hip"
-#include "build/f32/kernels.hip"  // generated: the same kernels in binary32, namespace rtd32 (tools/make_f32_sources.py)
+#include "device/shading.h"  // geom.h (k_wf_collect re-runs a winner's own test) + the shading-feature masks
+#include "kernels_api.h"     // the kernels themselves are instantiated in tu/*.hip
 
 using namespace rtd;
+
+namespace rtk {
+KernelTable& kernel_table() {
+    static KernelTable t{};
+    return t;
+}
+}  // namespace rtk
 
 // ------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
@@ -53,8 +60,12 @@ struct Lane {
     hipStream_t stream = nullptr;
     uint32_t capacity = 0;
     void* pool = nullptr;
+    uint32_t pool_cls = 0;  // class lists the pool was laid out for
     PathState st[2] = {};
     uint32_t* queue[2] = {nullptr, nullptr};
+    Lists lists{};          // class lists + fold lists (scene_dev.h)
+    uint32_t slot_cap = 0;  // records per pool = capacity + room for the unused ends of the waves' chunks
+    uint32_t q_cap = 0;     // entries per ray queue
     Ctl* ctl = nullptr;
     MirrorEntry* mirror_h = nullptr;  // pinned + mapped: counters published by k_trace
     MirrorEntry* mirror_d = nullptr;
@@ -118,6 +129,9 @@ struct rt_scene {
     std::vector<rt_light> lights;
     bool committed = false;
     int shade_variant = 0;  // index into kFeatVariants: the smallest shading-kernel instance that covers the scene
+    // vertex classes (scene_dev.h): class 0 = escaped; cls[k] for k >= 1 = {kernel instance, kind of hit record}
+    uint32_t n_cls = 1;
+    ClsDesc cls[kMaxCls] = {};
     // device
     std::vector<void*> allocs;
     DevScene dev{};
@@ -125,8 +139,10 @@ struct rt_scene {
     std::vector<rt_scene*> replicas;  // multi-device context: the device copies on ctx->peers[i] (no host data)
 };
 
-// (test hook: RT_TEST_POOL_OOM_ABOVE=<log2> makes pools of more than 2^log2 paths fail as if the memory were not
-// there, so that tests/test_gpu_abi2.py can walk the default pool's fall-back without 288 GB of other allocations)
+#ifdef RT_TEST_HOOKS
+// (librt_amd_testhooks.so only -- csrc/Makefile: RT_TEST_POOL_OOM_ABOVE=<log2> makes pools of more than 2^log2 paths fail as if
+// the memory were not there, so that tests/test_gpu_abi2.py can walk the default pool's fall-back without 288 GB of other
+// allocations.  The product library does not read the variable.)
 static uint32_t test_pool_oom_above() {
     static const uint32_t v = [] {
         const char* e = getenv("RT_TEST_POOL_OOM_ABOVE");
@@ -134,43 +150,57 @@ static uint32_t test_pool_oom_above() {
     }();
     return v;
 }
+#else
+static uint32_t test_pool_oom_above() { return 0u; }
+#endif
 
-static int ensure_lane_capacity(rt_context* c, Lane& ln, uint32_t cap) {
-    if (ln.capacity >= cap) return RT_OK;
+// bytes of one lane's pool for `cap` paths in flight and `n_cls` vertex classes
+static void pool_layout(uint32_t cap, uint32_t n_cls, size_t& slots, size_t& qn, size_t& bytes) {
+    // every shading wave may leave the end of its last chunk of slots / queue entries / list entries unused: at most 1/16
+    // of a launch's entries per kernel (kernels.hip: pick_chunk), summed generously
+    slots = (size_t)cap + cap / 8 + 65536;
+    qn = 3 * slots;
+    bytes = slots * (2 * (size_t)kRecBytes + 2 * sizeof(uint32_t)) + 2 * qn * sizeof(uint32_t) + (size_t)n_cls * slots * sizeof(ListEnt) + 4096;
+}
+
+static int ensure_lane_capacity(rt_context* c, Lane& ln, uint32_t cap, uint32_t n_cls) {
+    if (ln.capacity >= cap && ln.pool_cls >= n_cls) {
+        ln.lists.n_cls = n_cls;
+        return RT_OK;
+    }
     if (test_pool_oom_above() && cap > test_pool_oom_above()) return fail(RT_ERR_OOM, "simulated: no memory for a pool of %u paths", cap);
     HIP_TRY(hipSetDevice(c->device));
+    cap = std::max(cap, ln.capacity);
+    const uint32_t want_cls = n_cls;
+    n_cls = std::max(n_cls, ln.pool_cls);
     if (ln.pool) {
         HIP_TRY(hipFree(ln.pool));
         ln.pool = nullptr;
         ln.capacity = 0;
+        ln.pool_cls = 0;
     }
-    // one slab: 2 x (27 double arrays, rng, 4 result arrays, flags, orig), 2 ray queues
-    const size_t n = cap;
-    const size_t bytes = n * (2 * (27 * 8 + 8 + 4 * 4 + 4 + 4) + 2 * 3 * 4) + 4096;
+    // one slab: 2 pools of 256-B records, 2 ray queues, the class lists, 2 fold lists
+    size_t slots, qn, bytes;
+    pool_layout(cap, n_cls, slots, qn, bytes);
     void* slab = nullptr;
     HIP_TRY(hipMalloc(&slab, bytes));  // (on failure ln.pool stays null and ln.capacity 0: the caller may retry smaller)
     ln.pool = slab;
     char* p = (char*)ln.pool;
     for (int b = 0; b < 2; b++) {
-        PathState& st = ln.st[b];
-        double** dptrs[] = {&st.ox, &st.oy, &st.oz, &st.dx, &st.dy, &st.dz, &st.spx, &st.spy, &st.spz,
-                            &st.pdx, &st.pdy, &st.pdz, &st.bx, &st.by, &st.bz, &st.lx, &st.ly, &st.lz,
-                            &st.ax, &st.ay, &st.az, &st.qx, &st.qy, &st.qz, &st.kx, &st.ky, &st.kz};
-        for (auto dp : dptrs) {
-            *dp = (double*)p;
-            p += n * 8;
-        }
-        st.rng = (uint64_t*)p; p += n * 8;
-        st.hit_prim = (int32_t*)p; p += n * 4;
-        st.hit_slot = (uint32_t*)p; p += n * 4;
-        st.sh_prim = (int32_t*)p; p += n * 4;
-        st.pr_prim = (int32_t*)p; p += n * 4;
-        st.flags = (uint32_t*)p; p += n * 4;
-        st.orig = (uint32_t*)p; p += n * 4;
+        ln.st[b].rec = p;
+        p += slots * kRecBytes;
     }
-    ln.queue[0] = (uint32_t*)p; p += n * 12;
-    ln.queue[1] = (uint32_t*)p; p += n * 12;
+    ln.lists.ent = (ListEnt*)p; p += (size_t)n_cls * slots * sizeof(ListEnt);
+    ln.queue[0] = (uint32_t*)p; p += qn * sizeof(uint32_t);
+    ln.queue[1] = (uint32_t*)p; p += qn * sizeof(uint32_t);
+    ln.lists.fold[0] = (uint32_t*)p; p += slots * sizeof(uint32_t);
+    ln.lists.fold[1] = (uint32_t*)p; p += slots * sizeof(uint32_t);
+    ln.lists.cap = (uint32_t)slots;
+    ln.lists.n_cls = want_cls;
+    ln.slot_cap = (uint32_t)slots;
+    ln.q_cap = (uint32_t)qn;
     ln.capacity = cap;
+    ln.pool_cls = n_cls;
     return RT_OK;
 }
 
@@ -481,6 +511,18 @@ __global__ __launch_bounds__(256) void k_make_leaf_trav(const double* __restrict
     o[15] = (unsigned long long)e;
 }
 
+// scene_dev.h: the vertex class of every leaf slot goes into bits 27-30 of its leaf_prim word (tab: per material, the
+// class of a mesh hit and of a sphere / rect hit)
+__global__ __launch_bounds__(256) void k_set_leaf_cls(uint32_t* leaf_prim, const LeafMeta* __restrict__ leaf_meta,
+                                                     const uint8_t* __restrict__ tab, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t e = leaf_prim[i] & (kIdxMask | kLeafOther);
+    const uint32_t mat = leaf_meta[i].mat_flags & kMetaMatMask;
+    const uint32_t c = tab[2u * mat + ((e & kLeafOther) ? 1u : 0u)];
+    leaf_prim[i] = e | (c << kClsShift);
+}
+
 static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cache);
 
 // ---- host BVH shared between the processes of one node (RT_BVH_CACHE=<directory>, e.g. /dev/shm/...)
@@ -728,12 +770,14 @@ static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cac
     d.n_texs = (uint32_t)s->texs.size();
     d.env.light = -1;
     int need = 0;  // shading.h: kFeat*
-    for (const rt_material& m : s->mats) {
-        if (m.kind == RT_MAT_PLASTIC) need |= kFeatMicro | kFeatTwo;
-        if (m.kind == RT_MAT_METAL) need |= kFeatMicro;
-        if (m.kind == RT_MAT_MIRROR) need |= kFeatSpec;
-        if (m.kind == RT_MAT_GLASS) need |= (m.f[0] != 0.0 || m.f[1] != 0.0) ? (kFeatTrans | kFeatMicro | kFeatTwo) : kFeatSpec;
-    }
+    auto mat_need = [](const rt_material& m) {
+        if (m.kind == RT_MAT_PLASTIC) return kFeatMicro | kFeatTwo;
+        if (m.kind == RT_MAT_METAL) return kFeatMicro;
+        if (m.kind == RT_MAT_MIRROR) return kFeatSpec;
+        if (m.kind == RT_MAT_GLASS) return (m.f[0] != 0.0 || m.f[1] != 0.0) ? (kFeatTrans | kFeatMicro | kFeatTwo) : kFeatSpec;
+        return 0;
+    };
+    for (const rt_material& m : s->mats) need |= mat_need(m);
     for (size_t i = 0; i < s->lights.size(); i++) {
         if (s->lights[i].kind != RT_LIGHT_INFINITE) continue;
         // Light::make_infinite_light's Distribution2D (light.rs:608-638), rebuilt from the texels
@@ -752,9 +796,50 @@ static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cac
     t->shade_variant = kNumFeatVariants - 1;
     for (int v = kNumFeatVariants - 1; v >= 0; v--)
         if ((need & ~kFeatVariants[v]) == 0) t->shade_variant = v;
+    int forced_variant = -1;
     if (const char* e = getenv("RT_SHADE_VARIANT")) {  // experiment: force a larger instance
         const int v = std::min(kNumFeatVariants - 1, std::max(0, atoi(e)));
-        if ((need & ~kFeatVariants[v]) == 0) t->shade_variant = v;
+        if ((need & ~kFeatVariants[v]) == 0) t->shade_variant = forced_variant = v;
+    }
+    // ---- vertex classes (scene_dev.h): {smallest kernel instance covering the material (and the environment light, a
+    // scene-wide feature), kind of hit record}, one class per combination the scene's primitives make
+    std::vector<uint8_t> cls_tab(2 * std::max<size_t>(1, s->mats.size()), 0);
+    {
+        auto variant_for = [&](int nd) {
+            if (forced_variant >= 0) return forced_variant;
+            int best = kNumFeatVariants - 1;
+            for (int v = kNumFeatVariants - 1; v >= 0; v--)
+                if ((nd & ~kFeatVariants[v]) == 0) best = v;
+            return best;
+        };
+        const bool one_class = getenv("RT_ONE_CLASS") != nullptr;  // experiment: no split by material / kind of hit
+        const int tri_kind = has_uv ? kKindAny : kKindMesh;
+        for (int pass = 0; pass < 2; pass++) {
+            // pass 1 (only when pass 0 needed more than 15 classes, or RT_ONE_CLASS): the scene-wide instance for everything
+            t->n_cls = 1;
+            std::fill(cls_tab.begin(), cls_tab.end(), (uint8_t)0);
+            bool ok = true;
+            for (const rt_primitive& p : s->prims) {
+                const bool tri = p.kind == RT_PRIM_TRIANGLE;
+                const int kind = (pass == 1 && one_class) ? kKindAny : (tri ? tri_kind : kKindOther);
+                const int v = pass == 0 ? variant_for(mat_need(s->mats[p.mat_index]) | (need & kFeatEnv)) : t->shade_variant;
+                uint8_t& slot = cls_tab[2 * (size_t)p.mat_index + (tri ? 0 : 1)];
+                if (slot) continue;
+                uint32_t k = 1;
+                for (; k < t->n_cls; k++)
+                    if (t->cls[k].variant == v && t->cls[k].kind == kind) break;
+                if (k == t->n_cls) {
+                    if (t->n_cls >= (uint32_t)kMaxCls) {
+                        ok = false;
+                        break;
+                    }
+                    t->cls[k] = ClsDesc{(uint8_t)v, (uint8_t)kind};
+                    t->n_cls++;
+                }
+                slot = (uint8_t)k;
+            }
+            if (ok && !(pass == 0 && one_class)) break;
+        }
     }
     uint64_t n_tri = 0;
     uint32_t depth = 0;
@@ -847,6 +932,13 @@ static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cac
         d.n_nodes = (uint32_t)cache.nodes.size();
         depth = cache.depth;
         n_tri = cache.n_tri;
+    }
+    if (np > 0) {  // the vertex class of every leaf slot, into its leaf_prim word (both builders leave the bits clear)
+        const uint8_t* d_tab = nullptr;
+        if ((rc = upload(t, cls_tab.data(), cls_tab.size(), &d_tab)) != RT_OK) return rc;
+        hipLaunchKernelGGL(k_set_leaf_cls, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, t->ctx->stream,
+                           const_cast<uint32_t*>(d.leaf_prim), d.leaf_meta, d_tab, (uint32_t)np);
+        HIP_TRY(hipGetLastError());
     }
     if (np > 0) {  // the traversal kernel's one-line-per-slot copy of the leaf slots (scene_dev.h: leaf_trav)
         double* trav = nullptr;
@@ -965,6 +1057,7 @@ struct RenderJob {
     std::atomic<bool> abort{false};
     std::atomic<bool> cancelled{false};  // rt_render_cfg.cancel was seen non-zero
     int trace_blocks;
+    int shade_blocks[kMaxCls];  // resident blocks of each class kernel (persistent grids); [0]: the light kernel
     bool count_trav;
     bool f32;  // RT_PRECISION_F32: the binary32 kernel set
     bool f32_gen, f32_trace, f32_shade, f32_tail;  // (debug: RT_F32_MIX picks the kernels that use it)
@@ -987,46 +1080,19 @@ static int lane_fail(Lane& ln, int code, const char* fmt, ...) {
         }                                                                                                   \
     } while (0)
 
-typedef void (*ShadeKernel)(DevScene, PathState, PathState, Ctl*, uint32_t, uint32_t, uint32_t*, double*, double*, double*,
-                            DevStats*);
-typedef void (*TailKernel)(DevScene, PathState, PathState, Ctl*, uint32_t, uint32_t, double*, double*, double*,
-                           DevStats*);
-typedef void (*TraceKernel)(DevScene, PathState, const uint32_t*, Ctl*, uint32_t, DevStats*, TraceTune, MirrorEntry*,
-                            uint32_t, const BatchCtl*, unsigned long long);
-typedef void (*GenKernel)(PathState, rt_camera, ChunkDesc, const uint32_t*, uint32_t*, const Ctl*);
-// The kernels exist twice: namespace rtd (binary64, the parity mode) and namespace rtd32 (the same sources in
-// binary32, RT_PRECISION_F32).  Path state, film staging and scene records are the same f64 arrays in both, so
-// the launch schedule below does not care which set it drives.
-#define RT_FEAT_SWITCH(NS, KERNEL, ...)                                        \
-    switch (v) {                                                               \
-        case 0: return NS::KERNEL<kFeatVariants[0] __VA_ARGS__>;               \
-        case 1: return NS::KERNEL<kFeatVariants[1] __VA_ARGS__>;               \
-        case 2: return NS::KERNEL<kFeatVariants[2] __VA_ARGS__>;               \
-        case 3: return NS::KERNEL<kFeatVariants[3] __VA_ARGS__>;               \
-        case 4: return NS::KERNEL<kFeatVariants[4] __VA_ARGS__>;               \
-        case 5: return NS::KERNEL<kFeatVariants[5] __VA_ARGS__>;               \
-        case 6: return NS::KERNEL<kFeatVariants[6] __VA_ARGS__>;               \
-        case 7: return NS::KERNEL<kFeatVariants[7] __VA_ARGS__>;               \
-        default: return NS::KERNEL<kFeatVariants[8] __VA_ARGS__>;              \
-    }
-#define RT_COMMA ,
-static ShadeKernel shade_kernel(int v, bool f32) {
-    if (f32) RT_FEAT_SWITCH(rtd32, k_shade)
-    RT_FEAT_SWITCH(rtd, k_shade)
-}
-static TailKernel tail_kernel(int v, bool count, bool f32) {
-    if (f32) {
-        if (count) RT_FEAT_SWITCH(rtd32, k_tail, RT_COMMA true)
-        RT_FEAT_SWITCH(rtd32, k_tail, RT_COMMA false)
-    }
-    if (count) RT_FEAT_SWITCH(rtd, k_tail, RT_COMMA true)
-    RT_FEAT_SWITCH(rtd, k_tail, RT_COMMA false)
-}
-static TraceKernel trace_kernel(bool count, bool simple, bool f32) {
-    if (f32) return count ? rtd32::k_trace<true, false> : (simple ? rtd32::k_trace<false, true> : rtd32::k_trace<false, false>);
-    return count ? rtd::k_trace<true, false> : (simple ? rtd::k_trace<false, true> : rtd::k_trace<false, false>);
-}
-static GenKernel generate_kernel(bool f32) { return f32 ? rtd32::k_generate : rtd::k_generate; }
+// The kernels exist twice: binary64 (namespace rtd, the parity mode) and binary32 (namespace rtd32, the same sources
+// transformed, RT_PRECISION_F32).  Path records, film staging and scene records are the same arrays in both, so the
+// launch schedule below does not care which set it drives.  kernels_api.h: the table the kernels' translation units fill.
+using rtk::ShadeClsKernel;
+using rtk::ShadeLightKernel;
+using rtk::TailKernel;
+using rtk::TraceKernel;
+using rtk::GenKernel;
+static ShadeClsKernel shade_cls_kernel(const ClsDesc& cd, bool f32) { return rtk::kernel_table().shade_cls[f32 ? 1 : 0][cd.variant][cd.kind]; }
+static ShadeLightKernel shade_light_kernel(bool env, bool f32) { return rtk::kernel_table().shade_light[f32 ? 1 : 0][env ? 1 : 0]; }
+static TailKernel tail_kernel(int v, bool count, bool f32) { return rtk::kernel_table().tail[f32 ? 1 : 0][v][count ? 1 : 0]; }
+static TraceKernel trace_kernel(bool count, bool simple, bool f32) { return rtk::kernel_table().trace[f32 ? 1 : 0][count ? 2 : (simple ? 0 : 1)]; }
+static GenKernel generate_kernel(bool f32) { return rtk::kernel_table().generate[f32 ? 1 : 0]; }
 
 // One lane's share of a batch: keep `pool` paths alive, topping up from the shared batch counter,
 // until the batch is exhausted and this lane's paths have all retired.
@@ -1106,18 +1172,18 @@ static int run_lane(RenderJob& job, int lane_id) {
                     // that are each as slow as their single longest ray
                                         const uint32_t tail_blocks = std::min((live + 255) / 256, (uint32_t)c->num_cus * 2u);  // persistent waves
                     hipLaunchKernelGGL(tail_kernel(job.s->shade_variant, job.count_trav, job.f32_tail), dim3(tail_blocks), dim3(256), 0, stream, job.s->dev, ln.st[0],
-                                       ln.st[1], ln.ctl, (uint32_t)it, cfg->max_depth, c->lf[0], c->lf[1], c->lf[2],
-                                       c->stats);
+                                       ln.st[1], ln.ctl, (uint32_t)it, cfg->max_depth, ln.queue[it & 1], ln.lists, c->lf[0], c->lf[1],
+                                       c->lf[2], c->stats);
                     break;
                 }
             }
         }
         // top up the pool with new camera samples, then trace and shade everything alive
-        hipLaunchKernelGGL(k_plan, dim3(1), dim3(1), 0, stream, ln.ctl, c->batch, (uint32_t)it, P, job.batch_total, c->stats);
+        hipLaunchKernelGGL(rtk::kernel_table().plan, dim3(1), dim3(1), 0, stream, ln.ctl, c->batch, (uint32_t)it, P, job.batch_total, c->stats);
         if (!exhausted_known)
             hipLaunchKernelGGL(generate_kernel(job.f32_gen), dim3(gen_blocks), dim3(256), 0, stream, ln.st[it & 1], job.cam, job.batch,
                                c->pix_list, ln.queue[it & 1], ln.ctl);
-        const uint32_t shade_blocks = std::max(1u, (bound_active + RT_SHADE_BLOCK - 1) / RT_SHADE_BLOCK);
+        const uint32_t shade_want = std::max(1u, (bound_active + 255u) / 256u);
         const uint32_t tblocks = std::max(
             1u, (uint32_t)std::min<uint64_t>((3ull * bound_active + 255) / 256, (uint64_t)job.trace_blocks));
         hipEvent_t a = nullptr, b = nullptr;
@@ -1133,15 +1199,20 @@ static int run_lane(RenderJob& job, int lane_id) {
         const uint32_t seq = seq0 + (uint32_t)it;
         hipLaunchKernelGGL(trace_kernel(job.count_trav, job.s->dev.simple_others != 0, job.f32_trace), dim3(tblocks), dim3(256), 0, stream,
                            job.s->dev, ln.st[it & 1], ln.queue[it & 1], ln.ctl, (uint32_t)it, c->stats, c->tune,
-                           no_mirror ? nullptr : ln.mirror_d, seq, c->batch, job.batch_total);
+                           no_mirror ? nullptr : ln.mirror_d, seq, c->batch, job.batch_total, ln.lists);
         if (!no_ev) {
             LANE_TRY(hipEventRecord(b, stream));
             ln.trace_ev.emplace_back(a, b);
         }
         ln.trace_launches++;
-        hipLaunchKernelGGL(shade_kernel(job.s->shade_variant, job.f32_shade), dim3(shade_blocks), dim3(RT_SHADE_BLOCK), 0, stream, job.s->dev, ln.st[it & 1],
-                           ln.st[(it + 1) & 1], ln.ctl, (uint32_t)it, cfg->max_depth, ln.queue[(it + 1) & 1], c->lf[0],
-                           c->lf[1], c->lf[2], c->stats);
+        // one kernel per vertex class, the heaviest instances first; then the paths that end without a vertex (escaped,
+        // fold only).  Persistent grids: a class with few paths this bounce costs a launch, not a grid of empty blocks.
+        for (uint32_t k = 1; k < job.s->n_cls; k++)
+            hipLaunchKernelGGL(shade_cls_kernel(job.s->cls[k], job.f32_shade), dim3(std::min(shade_want, (uint32_t)job.shade_blocks[k])), dim3(256), 0,
+                               stream, job.s->dev, ln.st[it & 1], ln.st[(it + 1) & 1], ln.ctl, (uint32_t)it, cfg->max_depth, ln.lists, k,
+                               ln.queue[(it + 1) & 1], ln.q_cap, ln.slot_cap, c->lf[0], c->lf[1], c->lf[2], c->stats);
+        hipLaunchKernelGGL(shade_light_kernel(job.s->dev.env.light >= 0, job.f32_shade), dim3(std::min(shade_want, (uint32_t)job.shade_blocks[0])), dim3(256),
+                           0, stream, job.s->dev, ln.st[it & 1], ln.ctl, (uint32_t)it, cfg->max_depth, ln.lists, c->lf[0], c->lf[1], c->lf[2]);
         if (!no_ev) {  // the shading kernel runs from event b (end of k_trace) to this one
             hipEvent_t e = get_event(ln.events, ln.ev_i++);
             if (!e) {
@@ -1265,7 +1336,7 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
             n_lanes = (batch_cap > (size_t)P) ? c->n_lanes : 1;
             P = (uint32_t)std::min<size_t>(P, (batch_cap + 63) & ~(size_t)63);
             int rc = RT_OK;
-            for (int i = 0; i < n_lanes && rc == RT_OK; i++) rc = ensure_lane_capacity(c, c->lanes[i], P);
+            for (int i = 0; i < n_lanes && rc == RT_OK; i++) rc = ensure_lane_capacity(c, c->lanes[i], P, s->n_cls);
             if (rc == RT_OK) break;
             const uint32_t floor_paths = test_pool_oom_above() ? 64u : (1u << 24);
             if (rc != RT_ERR_OOM || !pool_default || P <= floor_paths) return rc;
@@ -1297,6 +1368,14 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
         int per_cu = std::max(1, occ);
         if (const char* e = getenv("RT_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));
         job.trace_blocks = c->num_cus * per_cu;
+        for (uint32_t k = 0; k < s->n_cls; k++) {
+            int so = 0;
+            if (k == 0)
+                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&so, shade_light_kernel(s->dev.env.light >= 0, job.f32), 256, 0));
+            else
+                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&so, shade_cls_kernel(s->cls[k], job.f32), 256, 0));
+            job.shade_blocks[k] = c->num_cus * std::max(1, so);
+        }
         size_t ev_i = 0;
         hipEvent_t ev_begin = get_event(c->events, ev_i++), ev_end = get_event(c->events, ev_i++);
         hipEvent_t ev_ready = get_event(c->events, ev_i++);
@@ -1348,7 +1427,7 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
                     }
                 }
                 // every lane has drained (run_lane synchronises its stream): add the batch to the film
-                hipLaunchKernelGGL(k_resolve, dim3((npx + 255) / 256), dim3(256), 0, stream, c->lf[0], c->lf[1], c->lf[2],
+                hipLaunchKernelGGL(rtk::kernel_table().resolve, dim3((npx + 255) / 256), dim3(256), 0, stream, c->lf[0], c->lf[1], c->lf[2],
                                    ck, c->pix_list, d_rgb, d_n);
                 HIP_TRY(hipGetLastError());
             }
@@ -1401,22 +1480,6 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
         stats->n_devices = 1;
         stats->shade_ms = shade_ms;
         stats->shade_launches = shade_launches;
-#ifdef RT_SHADE_PROF
-        {
-            unsigned long long pr[16];
-            if (hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_shade_prof), sizeof(pr)) == hipSuccess) {
-                static const char* names[10] = {"a:load+fold", "a:record", "a:emitted", "b:scattering", "b:nee-light",
-                                                "b:nee-bsdf", "b:continue", "b:store", "alloc", "queue"};
-                unsigned long long tot = 0;
-                for (int i = 0; i < 10; i++) tot += pr[i];
-                fprintf(stderr, "[shade prof] wave-cycles (100 MHz ticks) total %llu:", tot);
-                for (int i = 0; i < 10; i++) fprintf(stderr, " %s %.1f%%", names[i], tot ? 100.0 * pr[i] / tot : 0.0);
-                fprintf(stderr, "\n");
-                unsigned long long z[16] = {0};
-                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_shade_prof), z, sizeof(z));
-            }
-        }
-#endif
         if (getenv("RT_DIAG")) {
             unsigned long long d[4] = {0, 0, 0, 0}, over64 = 0, over256 = 0;
             for (int i = 0; i < kStatShards; i++) {
@@ -1677,32 +1740,33 @@ __global__ __launch_bounds__(256) void k_wf_setup(const rt_ray* __restrict__ ray
     }
     if (i >= n) return;
     const rt_ray r = rays[i];
-    // (the fast mode keeps binary32 values in the low half of each state slot, kernels.hip: ld3 / st3)
-    auto put = [&](double* a, double v) {
-        if (f32)
-            reinterpret_cast<float*>(a)[2u * i] = (float)v;
-        else
-            a[i] = v;
+    // (the fast mode keeps binary32 values in the low half of each word of a record, kernels.hip: w2r / r2w)
+    unsigned long long* w = reinterpret_cast<unsigned long long*>(st.rec + (size_t)i * kRecBytes);
+    auto put3 = [&](int at, const double* v) {
+        for (int k = 0; k < 3; k++)
+            w[at + k] = f32 ? (unsigned long long)__float_as_uint((float)v[k]) : (unsigned long long)__double_as_longlong(v[k]);
     };
-    put(st.ox, r.origin[0]); put(st.oy, r.origin[1]); put(st.oz, r.origin[2]);
+    put3(kWO, r.origin);
     // the three ray kinds of the render read their direction from different fields: spread the rays over two of them
     // (an extension ray and a probe ray are both traced on [SMALL, inf) -- a shadow ray is not a free-form ray)
     if (i & 1u) {
-        put(st.pdx, r.dir[0]); put(st.pdy, r.dir[1]); put(st.pdz, r.dir[2]);
+        put3(kWPd, r.dir);
         queue[i] = i | (kRayProbe << 30);
     } else {
-        put(st.dx, r.dir[0]); put(st.dy, r.dir[1]); put(st.dz, r.dir[2]);
+        put3(kWD, r.dir);
         queue[i] = i | (kRayExt << 30);
     }
-    st.hit_prim[i] = -2;
-    st.pr_prim[i] = -2;
+    int32_t* res = reinterpret_cast<int32_t*>(w + kWRes);  // {sh_prim, pr_prim}, {hit_prim, hit word}
+    res[1] = -2;
+    res[2] = -2;
 }
 __global__ __launch_bounds__(256) void k_wf_collect(DevScene sc, const rt_ray* __restrict__ rays, uint32_t n, PathState st,
                                                     rt_hit* hits) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const rt_ray r = rays[i];
-    const int32_t prim = (i & 1u) ? st.pr_prim[i] : st.hit_prim[i];
+    const int32_t* res = reinterpret_cast<const int32_t*>(st.rec + (size_t)i * kRecBytes + 8u * kWRes);
+    const int32_t prim = (i & 1u) ? res[1] : res[2];
     rt_hit h;
     h.prim = prim;
     h.t = kInf;
@@ -1749,7 +1813,7 @@ int rt_intersect_batch_ex(rt_context* c, rt_scene* s, const rt_ray* rays, uint64
     e = hipMemcpyAsync(d_rays, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess && wavefront) {
         Lane& ln = c->lanes[0];
-        rc = ensure_lane_capacity(c, ln, (uint32_t)((n + 63) & ~(uint64_t)63));
+        rc = ensure_lane_capacity(c, ln, (uint32_t)((n + 63) & ~(uint64_t)63), 1u);
         if (rc == RT_OK) {
             const unsigned blocks = (unsigned)((n + 255) / 256);
             int occ = 0;
@@ -1758,17 +1822,15 @@ int rt_intersect_batch_ex(rt_context* c, rt_scene* s, const rt_ray* rays, uint64
             const unsigned tblocks = std::max(1u, std::min(blocks, (unsigned)(c->num_cus * std::max(1, occ))));
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(k_wf_setup, dim3(blocks), dim3(256), 0, c->stream, d_rays, (uint32_t)n, ln.st[0], ln.queue[0], ln.ctl, f32 ? 1 : 0);
+                // (no class lists: the extension rays' results go into their records, kernels.hip: k_trace)
                 hipLaunchKernelGGL(tk, dim3(tblocks), dim3(256), 0, c->stream, s->dev, ln.st[0], ln.queue[0], ln.ctl, 0u, c->stats,
-                                   c->tune, (MirrorEntry*)nullptr, 0u, c->batch, 0ull);
+                                   c->tune, (MirrorEntry*)nullptr, 0u, c->batch, 0ull, Lists{});
                 hipLaunchKernelGGL(k_wf_collect, dim3(blocks), dim3(256), 0, c->stream, s->dev, d_rays, (uint32_t)n, ln.st[0], d_hits);
                 e = hipGetLastError();
             }
         }
     } else if (e == hipSuccess) {
-        if (f32)
-            hipLaunchKernelGGL(rtd32::k_intersect_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, s->dev, d_rays, n, d_hits);
-        else
-            hipLaunchKernelGGL(rtd::k_intersect_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, s->dev, d_rays, n, d_hits);
+        hipLaunchKernelGGL(rtk::kernel_table().intersect[f32 ? 1 : 0], dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, s->dev, d_rays, n, d_hits);
         e = hipGetLastError();
     }
     if (rc == RT_OK && e == hipSuccess) e = hipMemcpyAsync(hits, d_hits, n * sizeof(rt_hit), hipMemcpyDeviceToHost, c->stream);
@@ -1794,7 +1856,7 @@ int rt_resolve_rgb8(rt_context* c, const double* rgb_sum, const uint32_t* n, uin
     if (e == hipSuccess) e = hipMemcpyAsync(d_rgb, rgb_sum, npix * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_n, n, npix * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_tonemap, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, c->stream, d_rgb, d_n, (uint64_t)npix, d_out);
+        hipLaunchKernelGGL(rtk::kernel_table().tonemap, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, c->stream, d_rgb, d_n, (uint64_t)npix, d_out);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(rgb8, d_out, npix * 3, hipMemcpyDeviceToHost, c->stream);

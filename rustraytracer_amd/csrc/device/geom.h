@@ -451,10 +451,20 @@ RTD bool prim_intersects(const DevScene& sc, int32_t index, D3 o, D3 dir, double
     h.light = pr.light_index;
     return true;
 }
-// Record of the extension ray's winner: `hs` is the leaf slot the traversal found it in.
-RTD bool hit_record(const DevScene& sc, int32_t index, uint32_t hs, D3 o, D3 dir, double tmin, double tmax, HitRec& h) {
-    if (!(hs & kLeafOther) && !sc.mesh_has_uv) return tri_record_slot(sc, hs, index, o, dir, tmax, h);
-    return prim_intersects(sc, index, o, dir, tmin, tmax, h);
+// The extension ray's result as ONE word (scene_dev.h: the hit word of a list entry): class bits and kLeafOther of the
+// leaf, and what the winner's record is rebuilt from -- the LEAF SLOT of a mesh hit, the PRIMITIVE INDEX of a sphere / rect.
+RTD uint32_t hit_word(int32_t prim, uint32_t best_slot) {
+    return (best_slot & kLeafOther) ? ((uint32_t)prim | (best_slot & ~kIdxMask)) : best_slot;
+}
+// Record of the extension ray's winner.  KIND (scene_dev.h: kKind*) = what the caller knows about its hits; a mesh whose
+// record needs the primitive (texture coordinates) finds it through the leaf slot.
+template <int KIND>
+RTD bool hit_record(const DevScene& sc, uint32_t hit, D3 o, D3 dir, double tmin, double tmax, HitRec& h) {
+    const uint32_t idx = hit & kIdxMask;
+    if (KIND == kKindMesh) return tri_record_slot(sc, idx, 0, o, dir, tmax, h);
+    if (KIND == kKindOther || (hit & kLeafOther)) return prim_intersects(sc, (int32_t)idx, o, dir, tmin, tmax, h);
+    if (!sc.mesh_has_uv) return tri_record_slot(sc, idx, 0, o, dir, tmax, h);
+    return prim_intersects(sc, (int32_t)(sc.leaf_prim[idx] & kIdxMask), o, dir, tmin, tmax, h);
 }
 
 // ---------------------------------------------------------------- traversal
@@ -556,7 +566,7 @@ struct Trav {
     TriRay trr;
     double tmin, tmax, best_t;
     int32_t best_prim, cur;
-    uint32_t best_slot;  // leaf slot of best_prim (| kLeafOther)
+    uint32_t best_slot;  // leaf slot of best_prim | the leaf_prim word's class bits and kLeafOther
     int sp;
     bool done;
 };
@@ -800,7 +810,7 @@ RTD void leaf_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
         TriRay trz = tv.trr;
         trz.s_z = ip.z;  // 1 / dir[kz]: the same value as tri_ray()'s s_z, so that need not stay in a register
         hit = !(tf <= tn) && tri_core_t(p0t, p1t, p2t, trz, tmax, t, b0, b1, b2);
-        pi = (int32_t)e;
+        pi = (int32_t)(e & kIdxMask);
         if (hit && sc.mesh_has_uv) {  // rare path: uv-degenerate rejection (hittable.rs:373-378)
             const rt_primitive& pr = sc.prims[pi];
             const DevMesh& m = sc.meshes[pr.mesh_index];
@@ -821,7 +831,7 @@ RTD void leaf_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
         // (Primitive::get_bounding_box) is re-derived with the constructor's arithmetic
         // (primitive.rs:66-68, 110-113, 161-164, 212-215): k -/+ SMALL, centre -/+ r.
         const D3 o = unpermute(tv.op, tv.trr.kz), inv = unpermute(tv.ip, tv.trr.kz);
-        pi = (int32_t)(e & ~kLeafOther);
+        pi = (int32_t)(e & kIdxMask);
         if (COUNT) tc->others++;
 #ifdef RT_F32
         const double v0 = tvp[0], v1 = tvp[1], v2 = tvp[2], v3 = tvp[3], v4 = tvp[4];
@@ -872,7 +882,7 @@ RTD void leaf_step(Trav& tv, const DevScene& sc, TravStack& ts, TravCount* tc) {
     if (hit && (tv.best_prim < 0 || t < tv.best_t || (t == tv.best_t && pi > tv.best_prim))) {
         tv.best_t = t;
         tv.best_prim = pi;
-        tv.best_slot = slot | (e & kLeafOther);
+        tv.best_slot = slot | (e & ~kIdxMask);  // + the leaf's vertex class and kLeafOther
     }
     // the rest of the leaf is the leaf (first + 1, count - 1): no separate cursor to keep in a register
     if (count > 1u)

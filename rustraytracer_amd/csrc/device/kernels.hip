@@ -1,24 +1,27 @@
 // kernels.hip -- the wavefront path-tracing kernels for gfx950 (wave64).
 //
 // A "batch" = up to kBatchMax camera samples of one block of pixels (the whole render when it
-// fits).  Each of the two lanes keeps up to `paths_in_flight` paths alive and runs, per iteration:
+// fits).  A lane keeps up to `paths_in_flight` paths alive and runs, per iteration:
 //   k_plan + k_generate  top the lane's pool up with the batch's next camera samples (streaming
 //            regeneration: every launch stays full until the batch's single final drain)
 //   k_trace  persistent waves pull 64-ray batches from the ray queue (one atomic per
 //            wave) and run the closest-hit traversal for the three root call sites
 //            of SURVEY.md 3.2: R1 extension (integrator.rs:388), R2 shadow
 //            (hittable.rs:25-39, Q13: closest hit, compared by prim index), R3 MIS
-//            probe (integrator.rs:615).  Output: one prim index per ray.
-//   k_shade  one lane per live path: folds the previous vertex's direct-light terms
-//            using the R2/R3 results, rebuilds the winning hit's record, applies the
-//            emitted-light rule, builds the BSDF, samples one light + MIS
+//            probe (integrator.rs:615).  A finished extension ray is appended to the LIST OF ITS
+//            VERTEX CLASS (scene_dev.h: escaped / mesh hit or sphere-rect hit of a material group).
+//   k_shade_light + one k_shade_cls per class  one lane per path of the class: folds the previous
+//            vertex's direct-light terms using the R2/R3 results, rebuilds the winning hit's record,
+//            applies the emitted-light rule, builds the BSDF, samples one light + MIS
 //            (integrator.rs:530-659), samples the continuation, Russian roulette
-//            (integrator.rs:375-445), then compacts survivors and their rays into the
-//            next queues with __ballot/__popcll prefix sums (one atomic per wave).
-// Path state is PHYSICALLY compacted every bounce: k_shade reads slot i of buffer X[it&1] and
-// writes survivors to consecutive slots of X[(it+1)&1], so every state access of every kernel
-// is a dense, coalesced SoA stream however few paths survive (a sparse in-place SoA costs a
-// whole 64-B HBM atom per 8-B field).  A retired path drops its radiance into lfinal[orig].
+//            (integrator.rs:375-445), and writes survivors and their rays to the next pool / queue.
+//            Every wave of a class kernel runs ONE class over the whole launch (round 4; rounds 1-3 dealt
+//            a block's 256 consecutive slots to its waves by class).
+// Path state: one 256-B record per slot (scene_dev.h), two pools that ping-pong per bounce: a class kernel
+// reads record `slot` of X[it&1] and writes the survivor to a freshly allocated slot of X[(it+1)&1].
+// Waves are independent: output slots, queue entries and list entries come from per-wave CHUNKS of the
+// shared counters (one scalar atomic per chunk, no block barrier anywhere); the unused end of a wave's last
+// chunk is filled with null entries.  A retired path drops its radiance into lfinal[orig].
 // The R2/R3 results never influence control flow or RNG draws of the path, only
 // additions into L, which is why they can be traced one iteration late.
 // Film: k_resolve sums each pixel's samples in sample order in f64 -- the order of
@@ -26,96 +29,120 @@
 // independent of how tiles are split over GPUs.
 #include "shading.h"
 
-#ifndef RT_SHADE_BLOCK
-#define RT_SHADE_BLOCK 256  // threads per k_shade block = the paths dealt among its waves by class.  Measured (profiles/r03_exp_shade_block.txt,
-                            // C4 / C3 k_shade ms): 64: 923 / 123, 128: 644 / 95.4, 192: 613 / 93.6, 256: 616 / 95.0, 384: 759 / 115 -- and a dealing window of 2-8
-                            // blocks (tools/experiments/r03_deal_window.patch): 787-1026 / 114-146, the gathered state loads cost more than the
-                            // purer waves save
-#endif
-#ifndef RT_SHADE_LAST_WAVE
-#define RT_SHADE_LAST_WAVE 1  // k_shade (dealing instances): no barrier before the queue reservation, the block's last wave writes it
-#endif
-#ifndef RT_QUEUE_BY_KIND
-#define RT_QUEUE_BY_KIND 1  // k_shade queues a block's rays kind by kind (0: wave by wave)
-#endif
 #ifndef RT_XCD_QUEUE
 #define RT_XCD_QUEUE 1  // the ray queue in eight parts, one per XCD (k_trace); 0 = one head for all waves
 #endif
 
 namespace rtd {
 
-// Ctl, BatchCtl, MirrorEntry, ChunkDesc, TraceTune, kRing: scene_dev.h (shared with the f32 kernels)
+// Ctl, BatchCtl, MirrorEntry, ChunkDesc, TraceTune, Lists, kRing: scene_dev.h (shared with the f32 kernels)
 
+// ---- path records (scene_dev.h: PathState).  Everything is moved as 8-byte words / aligned 16-byte pairs; the fast
+// mode keeps binary32 values in the low half of a word (no v_cvt per field and bounce; the launch schedule and the
+// pools are shared with the parity mode).
+typedef unsigned long long rt_w;
+typedef rt_w rt_w2 __attribute__((ext_vector_type(2)));
 #ifdef RT_F32
-// Fast mode: the path state keeps its f64-sized slots (the launch schedule and the pools are shared with the parity
-// mode) but holds binary32 values in the low half of each slot -- no v_cvt_f32_f64 / v_cvt_f64_f32 per field and bounce.
-RTD D3 ld3(const f64_t* x, const f64_t* y, const f64_t* z, uint32_t i) {
-    return d3(reinterpret_cast<const float*>(x)[2u * i], reinterpret_cast<const float*>(y)[2u * i],  // RT_KEEP_F64
-              reinterpret_cast<const float*>(z)[2u * i]);                                            // RT_KEEP_F64
-}
-RTD void st3(f64_t* x, f64_t* y, f64_t* z, uint32_t i, D3 v) {
-    reinterpret_cast<float*>(x)[2u * i] = v.x;  // RT_KEEP_F64
-    reinterpret_cast<float*>(y)[2u * i] = v.y;  // RT_KEEP_F64
-    reinterpret_cast<float*>(z)[2u * i] = v.z;  // RT_KEEP_F64
-}
+RTD double w2r(rt_w w) { return __uint_as_float((uint32_t)w); }
+RTD rt_w r2w(double v) { return (rt_w)__float_as_uint(v); }
 #else
-RTD D3 ld3(const f64_t* x, const f64_t* y, const f64_t* z, uint32_t i) { return d3(x[i], y[i], z[i]); }
-RTD void st3(f64_t* x, f64_t* y, f64_t* z, uint32_t i, D3 v) {
-    x[i] = v.x;
-    y[i] = v.y;
-    z[i] = v.z;
-}
+RTD double w2r(rt_w w) { return __longlong_as_double((long long)w); }
+RTD rt_w r2w(double v) { return (rt_w)__double_as_longlong(v); }
 #endif
+RTD rt_w* rec_words(const PathState& st, uint32_t slot) { return reinterpret_cast<rt_w*>(st.rec + (size_t)slot * kRecBytes); }
+// a vec3 at word W: one aligned pair and one word, whichever way round W's parity puts them
+template <int W>
+RTD D3 ld3w(const rt_w* r) {
+    if (W & 1) {
+        const rt_w a = r[W];
+        const rt_w2 b = *reinterpret_cast<const rt_w2*>(r + W + 1);
+        return d3(w2r(a), w2r(b.x), w2r(b.y));
+    }
+    const rt_w2 a = *reinterpret_cast<const rt_w2*>(r + W);
+    const rt_w b = r[W + 2];
+    return d3(w2r(a.x), w2r(a.y), w2r(b));
+}
+template <int W>
+RTD void st3w(rt_w* r, D3 v) {
+    rt_w2 q;
+    if (W & 1) {
+        r[W] = r2w(v.x);
+        q.x = r2w(v.y);
+        q.y = r2w(v.z);
+        *reinterpret_cast<rt_w2*>(r + W + 1) = q;
+    } else {
+        q.x = r2w(v.x);
+        q.y = r2w(v.y);
+        *reinterpret_cast<rt_w2*>(r + W) = q;
+        r[W + 2] = r2w(v.z);
+    }
+}
+RTD void st_meta(rt_w* r, uint64_t rng, uint32_t orig, uint32_t flags) {
+    rt_w2 q;
+    q.x = rng;
+    q.y = (rt_w)orig | ((rt_w)flags << 32);
+    *reinterpret_cast<rt_w2*>(r + kWRng) = q;
+}
+// a record's pairs in registers (the fields a kernel wants are fetched up front, independent of each other)
+struct RecRegs {
+    rt_w2 p[16];
+};
+template <int W>
+RTD double recw(const RecRegs& R) { return w2r((W & 1) ? R.p[W >> 1].y : R.p[W >> 1].x); }
+template <int W>
+RTD D3 rec3(const RecRegs& R) { return d3(recw<W>(R), recw<W + 1>(R), recw<W + 2>(R)); }
 
 // Wave-uniform fetch-and-add on the SCALAR memory path (s_atomic_add, gfx9 family incl. gfx950; checked against
 // vector atomics on the same word by tools/experiments/satomic_test.hip).  Its return travels through lgkmcnt, so
 // the wave does not wait for its vector stores in flight (a vector atomic's return shares vmcnt with them and comes
 // back in order behind them).  Executes once per wave whatever EXEC is: call it from wave-uniform control flow only.
-// Not for the per-block counters of k_shade: there the scalar path is slower (C2 +8 % frame time) -- many more
-// atomics per launch on one word, and their return was not what the block waits for.
 RTD uint32_t wave_atomic_add(uint32_t* p, uint32_t v) {
     uint32_t ret = __builtin_amdgcn_readfirstlane(v);
     asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(ret) : "s"(p) : "memory");
     return ret;
 }
-// wave-level compaction: lanes with pred append `value` to out[]; one atomic per wave
-RTD void wave_append(bool pred, uint32_t value, uint32_t* out, uint32_t* counter) {
-    const unsigned long long mask = __ballot(pred);
-    if (mask == 0ull) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    const int leader = __ffsll((long long)mask) - 1;
-    uint32_t base = 0;
-    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader, 64);
-    if (pred) out[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = value;
+// ---- per-wave chunks of a shared counter.  Same-address atomics saturate near 88 per microsecond on this chip
+// (profiles/r03_exp_atomic_load.txt: rounds 1-3 ran k_shade's two list counters at 77 % of that), so a wave takes
+// `chunk` consecutive indices per atomic and hands them out itself; a request that does not fit the rest of the chunk is
+// SPLIT over the old and a new chunk, so only the end of a wave's LAST chunk stays unused (the caller fills it with
+// null entries).  chunk = 0: exact requests, one atomic each (small launches: no unused ends at all).
+struct Cursor {
+    uint32_t cur, end;
+};
+// entries per atomic, sized so that the unused ends of all waves together stay below n / 16
+RTD uint32_t pick_chunk(uint32_t n, uint32_t n_waves) {
+    const uint32_t c = n / (n_waves * 16u);
+    if (c < 64u) return 0u;
+    return c >= 512u ? 512u : (c >= 256u ? 256u : (c >= 128u ? 128u : 64u));
 }
-// wave-level allocation: lanes with pred get consecutive indices from *counter (one atomic per wave)
-RTD uint32_t wave_alloc(bool pred, uint32_t* counter) {
-    const unsigned long long mask = __ballot(pred);
-    if (mask == 0ull) return 0u;
-    const uint32_t lane = threadIdx.x & 63u;
-    const int leader = __ffsll((long long)mask) - 1;
-    uint32_t base = 0;
-    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader, 64);
-    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+// wave-uniform: c, chunk, cnt (1..64 <= chunk); the lanes that take part pass rank = 0 .. cnt-1
+RTD uint32_t cursor_take(Cursor& c, uint32_t* counter, uint32_t chunk, uint32_t cnt, uint32_t rank) {
+    if (chunk == 0u) return wave_atomic_add(counter, cnt) + rank;
+    const uint32_t rem = c.end - c.cur;
+    uint32_t idx = c.cur + rank;
+    if (cnt > rem) {
+        const uint32_t base = wave_atomic_add(counter, chunk);
+        if (rank >= rem) idx = base + (rank - rem);
+        c.cur = base + (cnt - rem);
+        c.end = base + chunk;
+    } else {
+        c.cur += cnt;
+    }
+    return idx;
 }
-RTD void wave_count(bool pred, unsigned long long* counter) {
-    const unsigned long long mask = __ballot(pred);
-    if (mask == 0ull) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    if ((int)lane == __ffsll((long long)mask) - 1) atomicAdd(counter, (unsigned long long)__popcll(mask));
+RTD void cursor_pad(const Cursor& c, uint32_t* arr, uint32_t cap) {
+    for (uint32_t i = c.cur + (threadIdx.x & 63u); i < c.end; i += 64u)
+        if (i < cap) arr[i] = kNullEntry;
 }
-// Same-address atomics saturate near 88 per microsecond on this chip, so the hot counters are
-// (a) aggregated per 256-thread block through LDS (one atomic per block) and (b) for the statistics,
-// spread over kStatShards cache lines that the host sums.
+// statistics go to kStatShards cache lines that the host sums
 RTD DevStats* stat_shard(DevStats* stats) { return stats + (blockIdx.x & (kStatShards - 1)); }
 
 // ------------------------------------------------------------------ generate
-#ifndef RT_F32  // (precision-independent: compiled once, in the f64 namespace)
+// (RT_KERNELS_CORE: the kernels that are not templates are compiled by ONE translation unit per precision, tu/tu_core.hip)
+#if defined(RT_KERNELS_CORE) && !defined(RT_F32)  // (precision-independent: compiled once, in the f64 namespace)
 // k_plan (one thread): how many camera samples this lane starts now = free pool slots, limited by
 // what the batch still holds; reserves them from the shared batch counter and appends them to the
-// path list / ray queue of iteration `it`.  Also clears the ring entries of iteration it+2.
+// pool / ray queue of iteration `it`.  Also clears the ring entries of iteration it+2.
 __global__ void k_plan(Ctl* ctl, BatchCtl* batch, uint32_t it, uint32_t pool, unsigned long long batch_total,
                        DevStats* stats) {
     const uint32_t r = it % kRing;
@@ -140,6 +167,8 @@ __global__ void k_plan(Ctl* ctl, BatchCtl* batch, uint32_t it, uint32_t pool, un
     ctl->n_rays[z] = 0;
     ctl->head[z] = 0;
     for (int x = 0; x < 8; x++) ctl->xhead[(it + 2) & 3u][x][0] = 0;
+    for (int c = 0; c < kMaxCls; c++) ctl->cls_count[(it + 2) & 3u][c][0] = 0;
+    ctl->fold_count[(it + 2) & 3u][0] = 0;
     if (want) {
         atomicAdd(&stats->paths, want);
         atomicAdd(&stats->r1, want);
@@ -148,6 +177,7 @@ __global__ void k_plan(Ctl* ctl, BatchCtl* batch, uint32_t it, uint32_t pool, un
 
 #endif
 
+#ifdef RT_KERNELS_CORE
 // integrator.rs:357-366 + sampler.rs:606-613 + geometry.rs:177-190 (+ util.rs:105-113)
 __global__ __launch_bounds__(256) void k_generate(PathState st, rt_camera cam, ChunkDesc ck,
                                                   const uint32_t* __restrict__ pix_list, uint32_t* queue,
@@ -182,15 +212,15 @@ __global__ __launch_bounds__(256) void k_generate(PathState st, rt_camera cam, C
     const D3 to = ulc + ho * u - vo * v;
     const D3 dir = to - origin;
     (void)rng_next(rng);  // rand_range(t0, t1)
-    st3(st.ox, st.oy, st.oz, slot, origin + offset);
-    st3(st.dx, st.dy, st.dz, slot, dir - offset);
-    // (beta = 1 and L = 0 are not written: kFresh tells shade_a -- 48 of this kernel's 116 B per sample, and the kernel
-    // is bound by its HBM writes)
-    st.rng[slot] = rng;
-    st.flags[slot] = kFresh;
-    st.orig[slot] = g;
+    // one whole 64-B atom of the record: o, d, rng, {orig, flags}.  beta = 1 and L = 0 are not written: kFresh tells
+    // shade_a (the kernel is bound by its HBM writes)
+    rt_w* r = rec_words(st, slot);
+    st3w<kWO>(r, origin + offset);
+    st3w<kWD>(r, dir - offset);
+    st_meta(r, rng, g, kFresh);
     queue[ctl->gen_q + idx] = slot | (kRayExt << 30);
 }
+#endif  // RT_KERNELS_CORE
 
 // --------------------------------------------------------------------- trace
 // Persistent waves, while-while traversal, dynamic ray replacement.
@@ -204,12 +234,16 @@ __global__ __launch_bounds__(256) void k_generate(PathState st, rt_camera cam, C
 //   * Every wave step is EITHER a node step OR a single-primitive step, whichever more lanes are
 //     waiting for (majority scheduling): the wave never runs the primitive code for the sake of a few
 //     lanes while the rest are walking the tree, and vice versa.
+//   * Results: a shadow / probe ray writes the primitive it found into its path's record; an extension ray is
+//     appended as {slot, hit word} to the list of the hit's vertex class (lists.ent; per-wave chunks per class, cursors in
+//     LDS).  lists.ent == null (k_tail does not use this kernel; rt_intersect_batch_ex does): the extension result goes
+//     into the record as well.
 // Every wave leaves the loop once the queue is exhausted and its own lanes are done.
 template <bool COUNT, bool SIMPLE>
 __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, PathState st, const uint32_t* __restrict__ queue,
                                                Ctl* ctl, uint32_t it_abs, DevStats* stats, TraceTune tune,
                                                MirrorEntry* mirror, uint32_t seq, const BatchCtl* batch,
-                                               unsigned long long batch_total) {
+                                               unsigned long long batch_total, Lists lists) {
     const uint32_t it = it_abs % kRing;
     const uint32_t n = ctl->n_rays[it];
     const unsigned long long t_start = COUNT ? wall_clock64() : 0ull;
@@ -221,25 +255,41 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
         mirror[it].remaining = rem > 0xffffffffull ? 0xffffffffu : (uint32_t)rem;
         __hip_atomic_store(&mirror[it].seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    // a block only joins the work-pulling loop if the queue can give it at least one batch:
-    // tail iterations with a handful of rays then cost a launch, not a grid of atomics
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t n_waves = gridDim.x * 4u;
+    uint32_t* const cls_counters = &ctl->cls_count[it_abs & 3u][0][0];
+    const uint32_t list_chunk = pick_chunk(n, n_waves);
     if (sc.n_nodes == 0) {  // a scene without primitives (an environment only): every query misses
-        for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-            const uint32_t e = queue[i];
+        for (uint32_t i0 = blockIdx.x * 256u + wave * 64u; i0 < n; i0 += gridDim.x * 256u) {
+            const uint32_t i = i0 + lane;
+            const uint32_t e = i < n ? queue[i] : kNullEntry;
             const uint32_t slot = e & kSlotMask, kind = e >> 30;
-            if (kind == kRayExt)
-                st.hit_prim[slot] = -1;
-            else if (kind == kRayShadow)
-                st.sh_prim[slot] = -1;
-            else
-                st.pr_prim[slot] = -1;
+            const bool ext = kind == kRayExt;
+            if (lists.ent) {
+                const unsigned long long m = __ballot(ext);
+                if (m) {
+                    const uint32_t at = wave_atomic_add(cls_counters, (uint32_t)__popcll(m)) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (ext && at < lists.cap) lists.ent[at] = ListEnt{slot, 0u};
+                }
+            } else if (ext) {
+                reinterpret_cast<int32_t*>(rec_words(st, slot) + kWHit)[0] = -1;
+            }
+            if (kind == kRayShadow) reinterpret_cast<int32_t*>(rec_words(st, slot) + kWRes)[0] = -1;
+            if (kind == kRayProbe) reinterpret_cast<int32_t*>(rec_words(st, slot) + kWRes)[1] = -1;
         }
         return;
     }
+    // a block only joins the work-pulling loop if the queue can give it at least one batch:
+    // tail iterations with a handful of rays then cost a launch, not a grid of atomics
     if (blockIdx.x * 256u >= n) return;
-    const uint32_t lane = threadIdx.x & 63u;
     TravCount tc{0, 0, 0};
     __shared__ int2 lds_stack[kLdsStack * 256];
+    // per wave and class: the wave's chunk of that class list ({next free entry, end})
+    __shared__ volatile uint32_t s_cls[4][kMaxCls][2];
+    if (lane < (uint32_t)kMaxCls) {
+        s_cls[wave][lane][0] = 0u;
+        s_cls[wave][lane][1] = 0u;
+    }
     RT_TRAV_STACK(ts, lds_stack)
 #if RT_LDS_NODES > 0
     // BASELINE north_star: "BVH-node tiles staged in LDS" -- the first RT_LDS_NODES nodes, the top of the tree, which
@@ -273,7 +323,6 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
     // 128-entry window were 5-10 % slower (the extra code in the refill path, and neighbouring queue entries are
     // neighbouring paths: small reservations let concurrent waves share their nodes in L2).
     // Small queues: shrink the reservation so that the tail still spreads over the waves.
-    const uint32_t n_waves = gridDim.x * 4u;
     uint32_t reserve = (uint32_t)tune.reserve;
     if (reserve > 128u) reserve = 128u;  // two cached entries per lane
     while (reserve > 64u && (uint64_t)reserve * n_waves * 4u > n) reserve >>= 1;
@@ -289,17 +338,38 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
         // Results are written in refill rounds only: a store in flight delays every later `s_waitcnt vmcnt`
         // (loads and stores share the counter), and some lane finishes in almost every round.
         if (n_idle >= tune.refill_lanes || exhausted) {
-            if (wb) {
-                const uint32_t slot = slot_kind & kSlotMask, kind = slot_kind >> 30;
-                if (kind == kRayExt) {
-                    st.hit_prim[slot] = tv.best_prim;
-                    st.hit_slot[slot] = tv.best_slot;
-                } else if (kind == kRayShadow)
-                    st.sh_prim[slot] = tv.best_prim;
-                else
-                    st.pr_prim[slot] = tv.best_prim;
-                wb = false;
+            const uint32_t slot = slot_kind & kSlotMask, kind = slot_kind >> 30;
+            const bool wb_ext = wb && kind == kRayExt;
+            if (lists.ent) {
+                // extension rays: {slot, hit word} goes to the list of the hit's class, class by class (a handful per round)
+                const uint32_t hw = tv.best_prim < 0 ? 0u : hit_word(tv.best_prim, tv.best_slot);
+                const uint32_t cls = hw >> kClsShift & (uint32_t)(kMaxCls - 1);
+                unsigned long long pend = __ballot(wb_ext);
+                while (pend) {
+                    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cls, __ffsll((long long)pend) - 1);
+                    const bool mine = wb_ext && cls == c;
+                    const unsigned long long m = __ballot(mine);
+                    pend &= ~m;
+                    Cursor cu;
+                    cu.cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cls[wave][c][0]);
+                    cu.end = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cls[wave][c][1]);
+                    const uint32_t at = cursor_take(cu, cls_counters + c * 32u, list_chunk, (uint32_t)__popcll(m),
+                                                    (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
+                    if (lane == 0) {
+                        s_cls[wave][c][0] = cu.cur;
+                        s_cls[wave][c][1] = cu.end;
+                    }
+                    if (mine && at < lists.cap) lists.ent[(size_t)c * lists.cap + at] = ListEnt{slot, hw};
+                }
+            } else if (wb_ext) {
+                int2 h;
+                h.x = tv.best_prim;
+                h.y = (int)(tv.best_prim < 0 ? 0u : hit_word(tv.best_prim, tv.best_slot));
+                *reinterpret_cast<int2*>(rec_words(st, slot) + kWHit) = h;
             }
+            if (wb && kind == kRayShadow) reinterpret_cast<int32_t*>(rec_words(st, slot) + kWRes)[0] = tv.best_prim;
+            if (wb && kind == kRayProbe) reinterpret_cast<int32_t*>(rec_words(st, slot) + kWRes)[1] = tv.best_prim;
+            wb = false;
         }
         if (!exhausted && (n_idle >= tune.refill_lanes)) {
             if (res_next >= res_end) {
@@ -340,8 +410,8 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
                 // the reservation's queue entries are fetched once, two per lane (reserve <= 128), and handed out
                 // with cross-lane reads: a refill then waits for the ray data only, not for queue -> ray data
                 res_base = base;
-                q_lo = base + lane < res_end ? queue[base + lane] : 0u;
-                q_hi = base + 64u + lane < res_end ? queue[base + 64u + lane] : 0u;
+                q_lo = base + lane < res_end ? queue[base + lane] : kNullEntry;
+                q_hi = base + 64u + lane < res_end ? queue[base + 64u + lane] : kNullEntry;
             }
             if (!exhausted) {
                 const uint32_t base = res_next;
@@ -351,20 +421,24 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
                 const uint32_t idx = base + my;
                 const uint32_t rel = idx - res_base;  // < 128 for the lanes that take an entry
                 const uint32_t e_lo = __shfl(q_lo, (int)(rel & 63u), 64), e_hi = __shfl(q_hi, (int)(rel & 63u), 64);
-                if (!has_ray && my < take) {
-                    const uint32_t e = rel < 64u ? e_lo : e_hi;
+                const uint32_t e = rel < 64u ? e_lo : e_hi;
+                // (an entry of kind kRayNone is the unused end of a shading wave's queue chunk: nothing to trace)
+                if (!has_ray && my < take && (e >> 30) != kRayNone) {
                     const uint32_t slot = e & kSlotMask, kind = e >> 30;
-                    D3 o = ld3(st.ox, st.oy, st.oz, slot);
+                    const rt_w* r = rec_words(st, slot);
+                    const rt_w2 p0 = *reinterpret_cast<const rt_w2*>(r), p1 = *reinterpret_cast<const rt_w2*>(r + 2);
+                    D3 o = d3(w2r(p0.x), w2r(p0.y), w2r(p1.x));
                     D3 d;
                     double tmin = kSmall;
                     if (kind == kRayExt) {
-                        d = ld3(st.dx, st.dy, st.dz, slot);
+                        const rt_w2 p2 = *reinterpret_cast<const rt_w2*>(r + 4);
+                        d = d3(w2r(p1.y), w2r(p2.x), w2r(p2.y));
                     } else if (kind == kRayShadow) {  // Visibility::unoccluded, hittable.rs:25-32
-                        d = ld3(st.spx, st.spy, st.spz, slot) - o;
+                        d = ld3w<kWSp>(r) - o;
                         o = o + d * kSmall;
                         tmin = 0.0;
                     } else {
-                        d = ld3(st.pdx, st.pdy, st.pdz, slot);
+                        d = ld3w<kWPd>(r);
                     }
                     trav_init(tv, sc, o, d, tmin, kInf);
                     slot_kind = e;
@@ -407,6 +481,14 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
             has_ray = false;
         }
     }
+    // the unused end of this wave's last chunk of every class list: null entries
+    if (lists.ent && list_chunk) {
+        for (uint32_t c = 0; c < lists.n_cls; c++) {
+            const uint32_t cur = s_cls[wave][c][0], end = s_cls[wave][c][1];
+            for (uint32_t i = cur + lane; i < end; i += 64u)
+                if (i < lists.cap) lists.ent[(size_t)c * lists.cap + i] = ListEnt{kNullEntry, 0u};
+        }
+    }
     if (COUNT) {
         if (blockIdx.x == 0 && threadIdx.x == 0 && n < 4096u) {  // diagnostic: in-kernel time of tail launches (10 ns ticks)
             atomicAdd(&stats->pad[0], wall_clock64() - t_start);
@@ -430,6 +512,7 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
     }
 }
 
+#ifdef RT_KERNELS_CORE
 // rt_intersect_batch: the same traversal on caller rays
 __global__ __launch_bounds__(256) void k_intersect_batch(DevScene sc, const rt_ray* __restrict__ rays, uint64_t n,
                                                          rt_hit* hits) {
@@ -450,49 +533,16 @@ __global__ __launch_bounds__(256) void k_intersect_batch(DevScene sc, const rt_r
                  ((tc.others > 255u ? 255u : tc.others) << 16);
     hits[i] = h;
 }
+#endif  // RT_KERNELS_CORE
 
 // --------------------------------------------------------------------- shade
-// The per-vertex work, split where k_shade needs a block barrier (output-slot allocation):
+// The per-vertex work in two halves:
 //   shade_a: fold the previous vertex's direct light (estimate_direct's two additions, using the R2/R3
 //            results), rebuild the record of the vertex the extension ray found, emitted-light rule.
 //   shade_b: BSDF, one-light NEE + MIS (integrator.rs:530-634), continuation sample, Russian roulette
-//            (integrator.rs:421-442); writes the survivor's state to slot `os` of `out`.
-// k_shade runs them for one bounce of every path; k_tail loops them per lane until the path retires.
-// Diagnostic build (-DRT_SHADE_PROF via tools/variants.sh, selected with RT_AMD_LIB): wave clock per section of
-// the shading code, printed by rt_render.  Note that time at the block barriers (sections "alloc", "queue") is
-// the wait for the slowest wave of the block, not issue time.
-#ifdef RT_SHADE_PROF
-__device__ unsigned long long g_shade_prof[16];
-struct ShadeProf {
-    unsigned long long acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long last = 0;
-};
-#define RT_PROF_DECL ShadeProf prof_; prof_.last = __builtin_readcyclecounter();
-#define RT_PROF_ARG , ShadeProf& prof_
-#define RT_PROF_PASS , prof_
-#define RT_PROF(k)                                                 \
-    {                                                              \
-        const unsigned long long now_ = __builtin_readcyclecounter(); \
-        prof_.acc[k] += now_ - prof_.last;                         \
-        prof_.last = now_;                                         \
-    }
-#define RT_PROF_FLUSH                                                                       \
-    for (int k_ = 0; k_ < 10; k_++) {                                                       \
-        unsigned long long v_ = prof_.acc[k_];                                              \
-        for (int o_ = 32; o_ > 0; o_ >>= 1) {                                               \
-            const unsigned long long w_ = __shfl_xor(v_, o_, 64);                           \
-            v_ = w_ > v_ ? w_ : v_;                                                         \
-        }                                                                                   \
-        if ((threadIdx.x & 63u) == 0 && v_) atomicAdd(&g_shade_prof[k_], v_);               \
-    }
-#else
-#define RT_PROF_DECL
-#define RT_PROF_ARG
-#define RT_PROF_PASS
-#define RT_PROF(k)
-#define RT_PROF_FLUSH
-#endif
-
+//            (integrator.rs:421-442); writes the survivor's state to record `os` of `out`.
+// The class kernels run them for one bounce of every path of their class; k_tail loops them per lane until the path
+// retires.  KIND (scene_dev.h: kKind*) says what kind of hit the caller's paths have, i.e. which record code is compiled in.
 struct ShadeA {
     D3 L, o, d, beta;
     HitRec rec;
@@ -502,62 +552,80 @@ struct ShadeA {
     bool live, spec, will_shade;
 };
 
-template <int FEAT>
-RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool valid, uint32_t max_depth, ShadeA& a RT_PROF_ARG) {
-    // Every field of the slot this function may need is fetched up front, unconditionally: the loads are
-    // independent and coalesced, so they cost one memory latency instead of one per branch level below.
-    const uint32_t ls = valid ? slot : 0u;  // (slot 0 always exists: the block would have exited otherwise)
-    const uint32_t fl_raw = in.flags[ls];
-    const D3 l_in = ld3(in.lx, in.ly, in.lz, ls), o_in = ld3(in.ox, in.oy, in.oz, ls);
-    const D3 d_in = ld3(in.dx, in.dy, in.dz, ls), beta_in = ld3(in.bx, in.by, in.bz, ls);
-    const int32_t hp_in = in.hit_prim[ls];
-    const uint32_t hs_in = in.hit_slot[ls];
-#ifdef RT_SHADE_COND_NEE
-    // (experiment) the pending-light block (80 of the slot's 244 bytes) only for slots that carry pending terms:
-    // a fresh camera sample and a path whose last vertex found no light to sample have none
-    int32_t sh_in = -1, pp_in = -1;
-    D3 a_in = black(), q_in = black(), k_in = black();
-    if (valid && (fl_raw & (kHasShadow | kHasProbe)) && !(fl_raw & kDead)) {
-        sh_in = in.sh_prim[ls];
-        pp_in = in.pr_prim[ls];
-        a_in = ld3(in.ax, in.ay, in.az, ls);
-        q_in = ld3(in.qx, in.qy, in.qz, ls);
-        k_in = ld3(in.kx, in.ky, in.kz, ls);
+// `hit` = the extension ray's hit word (scene_dev.h), `some` = it hit something; both ignored for a fold-only path.
+template <int FEAT, int KIND>
+RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, uint32_t hit, bool some, bool valid, uint32_t max_depth,
+                 ShadeA& a) {
+    // Every field of the record this function may need is fetched up front, unconditionally: the loads are
+    // independent, so they cost one memory latency instead of one per branch level below.  (A lane without a path reads
+    // record 0, which always exists.)  kKindNone -- escaped and fold-only paths, most of which need L and the film slot
+    // only -- fetches those first and the pending-light block on demand.
+    const rt_w* r = rec_words(in, valid ? slot : 0u);
+    const rt_w2* rp = reinterpret_cast<const rt_w2*>(r);
+    RecRegs R;
+    R.p[3] = rp[3];
+    R.p[8] = rp[8];
+    R.p[9] = rp[9];
+    if (KIND != kKindNone) {
+        R.p[0] = rp[0];
+        R.p[1] = rp[1];
+        R.p[2] = rp[2];
+        R.p[5] = rp[5];
+        R.p[6] = rp[6];
+        R.p[7] = rp[7];
+        R.p[10] = rp[10];
+        R.p[11] = rp[11];
+        R.p[12] = rp[12];
+        R.p[13] = rp[13];
     }
-#else
-    const int32_t sh_in = in.sh_prim[ls], pp_in = in.pr_prim[ls];
-    const D3 a_in = ld3(in.ax, in.ay, in.az, ls), q_in = ld3(in.qx, in.qy, in.qz, ls), k_in = ld3(in.kx, in.ky, in.kz, ls);
-#endif
-    a.rng = in.rng[ls];
-    a.orig = in.orig[ls];
-    a.fl = valid ? fl_raw : kDead;
-    const uint32_t fl = a.fl;
-    a.live = valid && !(fl & kDead);
+    a.rng = R.p[3].x;
+    a.orig = (uint32_t)R.p[3].y;
+    const uint32_t fl = valid ? (uint32_t)(R.p[3].y >> 32) : 0u;
+    a.fl = fl;
+    a.live = valid;
     a.L = black();
     a.o = black();
+    if (KIND == kKindNone) {
+        if (valid && (fl & (kHasShadow | kHasProbe))) {
+            R.p[0] = rp[0];
+            R.p[1] = rp[1];
+            R.p[7] = rp[7];
+            R.p[10] = rp[10];
+            R.p[11] = rp[11];
+            R.p[12] = rp[12];
+            R.p[13] = rp[13];
+        }
+        if (((FEAT & kFeatEnv) != 0) && valid && !(fl & kFoldOnly)) {  // an escaped ray sees the environment
+            R.p[1] = rp[1];
+            R.p[2] = rp[2];
+            R.p[5] = rp[5];
+            R.p[6] = rp[6];
+        }
+    }
     if (a.live) {
-        a.L = (fl & kFresh) ? black() : l_in;
-        a.o = o_in;
+        a.L = (fl & kFresh) ? black() : rec3<kWL>(R);
         // ---- fold the previous vertex's direct lighting
         if (fl & (kHasShadow | kHasProbe)) {
+            a.o = rec3<kWO>(R);
             const uint32_t light_idx = fl >> kLightShift;
             const rt_light& lt = sc.lights[light_idx];
             const bool infinite = ((FEAT & kFeatEnv) != 0) && lt.kind == RT_LIGHT_INFINITE;
             D3 ld = black();
             if (fl & kHasShadow) {
                 // Visibility::unoccluded(infinite): an area light must be the closest hit, the environment needs a miss
-                const int32_t sh = sh_in;
-                if (infinite ? sh < 0 : sh == (int32_t)lt.prim_index) ld = ld + a_in;
+                const int32_t sh = (int32_t)(uint32_t)R.p[7].x;
+                if (infinite ? sh < 0 : sh == (int32_t)lt.prim_index) ld = ld + rec3<kWA>(R);
             }
             if (fl & kHasProbe) {
-                const int32_t pp = pp_in;
+                const int32_t pp = (int32_t)(uint32_t)(R.p[7].x >> 32);
+                const D3 q_in = rec3<kWQ>(R);
                 if (infinite) {
                     // integrator.rs:617-630: an escaped probe sees light.le(ray), already folded into q by shade_b
                     if (pp < 0) ld = ld + q_in;
                 } else if (pp >= 0) {
                     const int32_t li = sc.prims[pp].light_index;
                     if (li >= 0 && (uint32_t)li == light_idx) {
-                        const D3 pd = ld3(in.pdx, in.pdy, in.pdz, slot);
+                        const D3 pd = ld3w<kWPd>(r);
                         const rt_primitive& lpr = sc.prims[pp];
                         if (lpr.kind >= RT_PRIM_XY_RECT && lpr.xform_index < 0) {
                             // axis-aligned rect emitter: the record's normal faces the ray (set_front), so
@@ -580,10 +648,9 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool va
                     }
                 }
             }
-            a.L = a.L + cmul(ld * (double)sc.n_lights, k_in);
+            a.L = a.L + cmul(ld * (double)sc.n_lights, rec3<kWK>(R));
         }
     }
-    RT_PROF(0)
     // ---- the vertex found by the extension ray
     const bool active = a.live && !(fl & kFoldOnly);
     a.d = black();
@@ -592,12 +659,13 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool va
     a.bounces = fl & kBounceMask;
     a.spec = (fl & kSpecular) != 0;
     if (active) {
-        const int32_t hp = hp_in;
-        a.d = d_in;
-        a.beta = (fl & kFresh) ? white() : beta_in;
-        is_some = hp >= 0;
-        if (is_some) is_some = hit_record(sc, hp, hs_in, a.o, a.d, kSmall, kInf, a.rec);
-        RT_PROF(1)
+        if (KIND != kKindNone || ((FEAT & kFeatEnv) != 0)) {
+            if (KIND != kKindNone) a.o = rec3<kWO>(R);
+            a.d = rec3<kWD>(R);
+            a.beta = (fl & kFresh) ? white() : rec3<kWBeta>(R);
+        }
+        is_some = KIND != kKindNone && some;
+        if (is_some) is_some = hit_record<KIND>(sc, hit, a.o, a.d, kSmall, kInf, a.rec);
         if (a.bounces == 0 || a.spec) {  // integrator.rs:396-411 (Q18)
             if (is_some) {
                 const int32_t li = a.rec.light;
@@ -609,7 +677,6 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, bool va
         }
     }
     a.will_shade = active && is_some && a.bounces < max_depth;
-    RT_PROF(2)
 }
 
 struct ShadeOut {
@@ -618,16 +685,15 @@ struct ShadeOut {
 
 // Precondition: a.will_shade.  `os` = slot of `out` reserved for this vertex.
 template <int FEAT>
-RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& out, uint32_t slot, uint32_t os,
-                     ShadeA& a RT_PROF_ARG) {
+RTD ShadeOut shade_b(const DevScene& sc, const PathState& out, uint32_t os, ShadeA& a) {
     const HitRec& rec = a.rec;
     D3 beta = a.beta;
     uint32_t bounces = a.bounces;
     bool spec = a.spec;
     uint64_t rng = a.rng;
+    rt_w* ow = rec_words(out, os);
     Bsdf bsdf;
     compute_scattering<FEAT>(sc, rec, bsdf);
-    RT_PROF(3)
     bool has_sh = false, has_pr = false;
     uint32_t light_num = 0;
     // ---- uniform_sample_one_light / estimate_direct (integrator.rs:530-634)
@@ -671,11 +737,10 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
             if (!is_black(f)) {
                 has_sh = true;
                 const double weight = power_heuristic(1, light_pdf, 1, scattering_pdf);
-                st3(out.ax, out.ay, out.az, os, cmul(f, color) * (weight / light_pdf));
-                st3(out.spx, out.spy, out.spz, os, sp);
+                st3w<kWA>(ow, cmul(f, color) * (weight / light_pdf));
+                st3w<kWSp>(ow, sp);
             }
         }
-        RT_PROF(4)
         {
             D3 f2, wi2;
             double spdf;
@@ -696,13 +761,12 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
                     has_pr = true;
                     // the radiance an escaped probe would see is a function of its direction only: fold it in now
                     const D3 pcol = infinite ? infinite_le(sc, lt, wi2) : ltcolor;
-                    st3(out.qx, out.qy, out.qz, os, is_black(pcol) ? black() : cmul(f2, pcol) * (weight / spdf));
-                    st3(out.pdx, out.pdy, out.pdz, os, wi2);
+                    st3w<kWQ>(ow, is_black(pcol) ? black() : cmul(f2, pcol) * (weight / spdf));
+                    st3w<kWPd>(ow, wi2);
                 }
             }
         }
-        if (has_sh || has_pr) st3(out.kx, out.ky, out.kz, os, beta);
-        RT_PROF(5)
+        if (has_sh || has_pr) st3w<kWK>(ow, beta);
     }
     // ---- continuation (integrator.rs:421-442)
     const D3 wo = -a.d;
@@ -724,48 +788,34 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
         }
         bounces = bounces + 1;
     }
-    RT_PROF(6)
     ShadeOut r;
     r.emit_ext = cont;
     r.emit_sh = has_sh;
     r.emit_pr = has_pr;
     r.keep = cont || has_sh || has_pr;
     if (r.keep) {
-        st3(out.ox, out.oy, out.oz, os, rec.p);  // spawn_ray: origin = hit point (Q4)
-        st3(out.lx, out.ly, out.lz, os, a.L);
+        st3w<kWO>(ow, rec.p);  // spawn_ray: origin = hit point (Q4)
+        st3w<kWL>(ow, a.L);
         if (cont) {
-            st3(out.dx, out.dy, out.dz, os, wi);
-            st3(out.bx, out.by, out.bz, os, beta);
-            out.rng[os] = rng;
+            st3w<kWD>(ow, wi);
+            st3w<kWBeta>(ow, beta);
         }
-        out.orig[os] = a.orig;
-        out.flags[os] = (bounces & kBounceMask) | (spec ? kSpecular : 0u) | (cont ? 0u : kFoldOnly) |
-                        (has_sh ? kHasShadow : 0u) | (has_pr ? kHasProbe : 0u) | (light_num << kLightShift);
-    } else {
-        out.flags[os] = kDead;
+        st_meta(ow, rng, a.orig,
+                (bounces & kBounceMask) | (spec ? kSpecular : 0u) | (cont ? 0u : kFoldOnly) | (has_sh ? kHasShadow : 0u) |
+                    (has_pr ? kHasProbe : 0u) | (light_num << kLightShift));
     }
-    RT_PROF(7)
     return r;
 }
 
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 2
 #endif
-#ifndef RT_SHADE4_MAXFEAT
-#define RT_SHADE4_MAXFEAT (-1)  // (experiment) instances up to this mask compiled for 4 waves/SIMD
-#endif
 #ifndef RT_SHADE3_MAXFEAT
 #define RT_SHADE3_MAXFEAT 3  // instances up to this feature mask are compiled for 3 waves/SIMD (measured: the
                              // two-lobe and row-f4 instances spill too much to gain from it)
 #endif
-#ifndef RT_SORT_CLASSES
-#define RT_SORT_CLASSES 5
-#endif
-#ifndef RT_SORT_FEAT0
-#define RT_SORT_FEAT0 0  // (experiment) the Lambert-only instance deals its paths too
-#endif
 #undef RT_SHADE_BOUND
-#define RT_SHADE_BOUND_RULE(F) ((F) <= RT_SHADE4_MAXFEAT ? 4 : (feat_three_waves(F) && RT_SHADE3_MAXFEAT >= 3 ? 3 : RT_SHADE_WAVES))
+#define RT_SHADE_BOUND_RULE(F) (feat_three_waves(F) && RT_SHADE3_MAXFEAT >= 3 ? 3 : RT_SHADE_WAVES)
 #ifdef RT_F32
 #ifndef RT_F32_SHADE_WAVES
 #define RT_F32_SHADE_WAVES 4  // the binary32 single-lobe instances need 127-138 VGPRs: 4 waves/SIMD with a few spills
@@ -775,272 +825,142 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& in, const PathState& o
 #else
 #define RT_SHADE_BOUND(F) RT_SHADE_BOUND_RULE(F)
 #endif
-template <int FEAT>
-__global__ __launch_bounds__(RT_SHADE_BLOCK, RT_SHADE_BOUND(FEAT)) void k_shade(DevScene sc, PathState in, PathState out, Ctl* ctl, uint32_t it_abs,
-                                               uint32_t max_depth, uint32_t* queue_out, f64_t* lfx, f64_t* lfy,
-                                               f64_t* lfz, DevStats* stats) {
-    const uint32_t it = it_abs % kRing, itn = (it_abs + 1) % kRing;
-    const uint32_t n_active = ctl->n_active[it];
-    // whole block past the end: nothing to do (block-uniform exit: the block barriers below stay well-formed)
-    if (blockIdx.x * blockDim.x >= n_active) return;
-    // (Giving every XCD one contiguous eighth of the path list here, as k_trace does with the ray queue, was measured
-    // and is 11-21 % slower for this kernel: C4 717 -> 871 ms, C3 109 -> 122.)
-    const uint32_t bid = blockIdx.x;
-    constexpr uint32_t kSW = RT_SHADE_BLOCK / 64;  // waves per block
-    __shared__ uint32_t s_cnt[kSW][4];  // [wave][0 = output slots, 1..3 = ext / shadow / probe rays]
-    __shared__ uint32_t s_base[2];    // block's base in the next path list / ray queue
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    // Deal the block's 256 paths to its lanes by what their vertex needs (mesh hit / sphere-rect hit / escaped /
-    // fold only / nothing), so that the lanes of a wave run the same branches: the shading kernels are VALU-bound
-    // at 24-35 active lanes of 64 (PMC).  Paths are independent and the film staging is indexed by
-    // (pixel, sample), so the order inside a block changes no result.  Scenes with Lambertian materials only
-    // (FEAT == 0, e.g. C2) have nothing to separate and skip it; C3 +3.8 %, C4 +2.7 %, material_hdr(1) +2.9 %.
-    uint32_t slot = bid * blockDim.x + threadIdx.x;
-    if (FEAT != 0 || RT_SORT_FEAT0) {
-        constexpr uint32_t kCls = RT_SORT_CLASSES;
-        __shared__ uint32_t s_cls[kSW][kCls];
-        __shared__ uint16_t s_perm[RT_SHADE_BLOCK];
-        uint32_t key = kCls - 1u;
-        if (slot < n_active) {
-            const uint32_t fl0 = in.flags[slot];
-            if (!(fl0 & kDead)) {
-                if (fl0 & kFoldOnly)
-                    key = kCls - 2u;
-                else if (in.hit_prim[slot] < 0)
-                    key = kCls - 3u;
-                else
-                {
-                    const uint32_t hs0 = in.hit_slot[slot];
-                    if (hs0 & kLeafOther)
-                        key = kCls - 4u;
-                    else  // mesh hit: with more than five classes also by material (two dragons of different materials)
-                        key = kCls > 5u ? (sc.leaf_meta[hs0].mat_flags & kMetaMatMask) % (kCls - 4u) : 0u;
-                }
-            }
-        }
-        uint32_t rank = 0;
-        const unsigned long long below = (1ull << lane) - 1ull;
-#pragma unroll
-        for (uint32_t c = 0; c < kCls; c++) {
-            const unsigned long long m = __ballot(key == c);
-            if (key == c) rank = (uint32_t)__popcll(m & below);
-            if (lane == 0) s_cls[wave][c] = (uint32_t)__popcll(m);
-        }
-        __syncthreads();
-        uint32_t dest = rank;
-#pragma unroll
-        for (uint32_t c = 0; c < kCls; c++) {
-#pragma unroll
-            for (uint32_t w = 0; w < kSW; w++) {
-                const uint32_t cnt = s_cls[w][c];
-                if (c < key || (c == key && w < wave)) dest += cnt;
-            }
-        }
-        s_perm[dest] = (uint16_t)threadIdx.x;
-        __syncthreads();
-        slot = bid * blockDim.x + s_perm[threadIdx.x];
-    }
-    ShadeA a;
-    RT_PROF_DECL
-    shade_a<FEAT>(sc, in, slot, slot < n_active, max_depth, a RT_PROF_PASS);
-    // a vertex that will be shaded gets its output slot now (dense, block-contiguous); if the path
-    // then ends without pending light terms the slot is marked dead and skipped next bounce
-    uint32_t os;
-    bool leader = threadIdx.x == 0;
-    __shared__ uint32_t s_alive[kSW];
-    __shared__ uint32_t s_done;            // waves of the block that have staged their rays
-    __shared__ uint32_t s_stage[kSW][3][64];  // [wave][kind][rank]: queue entries waiting for the block's reservation
-    {   // one atomic per block: wave counts -> LDS -> block base -> per-lane slot
+
+// One vertex class of one bounce (scene_dev.h): the paths of list `cls`, which k_trace filled with the extension rays
+// that hit a primitive of that class.  FEAT = the shading features the class's materials need (so a class of glass does
+// not carry the microfacet code, nor a Lambertian floor the glass code), KIND = mesh slot / sphere-rect / generic record.
+// Persistent, barrier-free: wave w takes the 64-entry groups w, w + n_waves, ... of the list; output slots, queue entries
+// (a chunk per ray kind, so a traversal wave's reservation is mostly one kind) and fold-list entries come from
+// per-wave chunks of the shared counters.
+template <int FEAT, int KIND>
+__global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade_cls(DevScene sc, PathState in, PathState out, Ctl* ctl, uint32_t it_abs,
+                                               uint32_t max_depth, Lists lists, uint32_t cls, uint32_t* queue_out, uint32_t q_cap,
+                                               uint32_t slot_cap, f64_t* lfx, f64_t* lfy, f64_t* lfz, DevStats* stats) {
+    const uint32_t itn = (it_abs + 1) % kRing;
+    const uint32_t n = ctl->cls_count[it_abs & 3u][cls][0];
+    const uint32_t n_groups = (n + 63u) / 64u;
+    const uint32_t lane = threadIdx.x & 63u, n_waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t wave_g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wave_g >= n_groups) return;
+    const uint32_t chunk = pick_chunk(n, n_waves < n_groups ? n_waves : n_groups);
+    const ListEnt* ent = lists.ent + (size_t)cls * lists.cap;
+    uint32_t* fold_out = lists.fold[(it_abs + 1u) & 1u];
+    uint32_t* const c_slots = &ctl->n_active[itn];
+    uint32_t* const c_rays = &ctl->n_rays[itn];
+    uint32_t* const c_fold = &ctl->fold_count[(it_abs + 1u) & 3u][0];
+    Cursor cs{0u, 0u}, cq0{0u, 0u}, cq1{0u, 0u}, cq2{0u, 0u}, cf{0u, 0u};
+    uint32_t n_r1 = 0, n_r2 = 0, n_r3 = 0, n_v = 0;  // wave-uniform
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint32_t g = wave_g; g < n_groups; g += n_waves) {
+        const uint32_t i = g * 64u + lane;
+        ListEnt e{kNullEntry, 0u};
+        if (i < n) e = ent[i];
+        const bool valid = e.slot != kNullEntry;  // (null: the unused end of a traversal wave's list chunk)
+        ShadeA a;
+        shade_a<FEAT, KIND>(sc, in, e.slot, e.hit, true, valid, max_depth, a);
         const unsigned long long m = __ballot(a.will_shade);
-        // A wave without a vertex to shade -- escaped / fold-only / dead paths, which the dealing step gathers into
-        // whole waves -- writes its film values, reports zero counts and ENDS instead of parking at the block's two
-        // barrier pairs (a barrier waits only for the waves that are still alive).  Parked waves hold their 168
-        // registers and a wave slot while the block's other waves run shade_b: C4 (42 % of the slots are escaped
-        // paths) k_shade 741 -> 658 ms, C3 110.6 -> 101.3; the Lambert-only instance does not deal and sees nothing.
-        if (m == 0ull) {
-            if (a.live) {
-                const uint32_t og = a.orig;
-                lfx[og] = a.L.x;
-                lfy[og] = a.L.y;
-                lfz[og] = a.L.z;
-            }
-            if (lane == 0) {
-                s_cnt[wave][0] = 0u;
-                s_cnt[wave][1] = 0u;
-                s_cnt[wave][2] = 0u;
-                s_cnt[wave][3] = 0u;
-                s_alive[wave] = 0u;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");  // the LDS writes have landed before the wave ends
-            RT_PROF(8)
-            RT_PROF_FLUSH
-            return;
+        uint32_t os = 0;
+        if (m) {
+            os = cursor_take(cs, c_slots, chunk, (uint32_t)__popcll(m), (uint32_t)__popcll(m & below));
+            n_v += (uint32_t)__popcll(m);
         }
-        if (lane == 0) {
-            s_cnt[wave][0] = (uint32_t)__popcll(m);
-            s_alive[wave] = 1u;
+        ShadeOut r{false, false, false, false};
+        if (a.will_shade && os < slot_cap) r = shade_b<FEAT>(sc, out, os, a);
+        if (a.live && !r.keep) {  // retired: its radiance goes to the film staging slot of (pixel, sample)
+            const uint32_t og = a.orig;
+            lfx[og] = a.L.x;
+            lfy[og] = a.L.y;
+            lfz[og] = a.L.z;
         }
-        __syncthreads();
-        // the block's leader is lane 0 of its first wave that is still alive
-        leader = lane == 0;
-        for (uint32_t w = 0; w < wave; w++) leader = leader && s_alive[w] == 0u;
-        if (leader) {
-            uint32_t tot = 0;
-            for (uint32_t w = 0; w < kSW; w++) tot += s_cnt[w][0];
-            s_base[0] = tot ? atomicAdd(&ctl->n_active[itn], tot) : 0u;
-            s_done = 0u;
-        }
-        __syncthreads();
-        uint32_t off = s_base[0];
-        for (uint32_t w = 0; w < wave; w++) off += s_cnt[w][0];
-        os = off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    }
-    RT_PROF(8)
-    ShadeOut r{false, false, false, false};
-    if (a.will_shade) r = shade_b<FEAT>(sc, in, out, slot, os, a RT_PROF_PASS);
-    if (a.live && !r.keep) {  // retired: its radiance goes to the film staging slot of (pixel, sample)
-        const uint32_t og = a.orig;
-        lfx[og] = a.L.x;
-        lfy[og] = a.L.y;
-        lfz[og] = a.L.z;
-    }
-    // ---- rays of the next bounce: one queue reservation per block, laid out as
-    // [extension][shadow][probe]; statistics: one atomic per block and counter, on this block's shard
-    {
+        // ---- rays of the next bounce, and the paths that only have light terms to fold
         const unsigned long long me = __ballot(r.emit_ext), ms = __ballot(r.emit_sh), mp = __ballot(r.emit_pr);
-        const uint32_t ce = (uint32_t)__popcll(me), cs = (uint32_t)__popcll(ms), cp = (uint32_t)__popcll(mp);
-        if (lane == 0) {
-            s_cnt[wave][1] = ce;
-            s_cnt[wave][2] = cs;
-            s_cnt[wave][3] = cp;
+        const unsigned long long mf = __ballot(r.keep && !r.emit_ext);
+        if (me) {
+            const uint32_t at = cursor_take(cq0, c_rays, chunk, (uint32_t)__popcll(me), (uint32_t)__popcll(me & below));
+            if (r.emit_ext && at < q_cap) queue_out[at] = os | (kRayExt << 30);
+            n_r1 += (uint32_t)__popcll(me);
         }
-        // No barrier in front of the queue reservation (instances with class dealing): a wave stages its entries in LDS
-        // and ENDS; the block's last wave to arrive (an LDS counter) reserves the queue range and writes everybody's
-        // entries.  A wave that has finished shade_b no longer holds its registers until the block's slowest wave has:
-        // k_shade -2.3 % on C4 and C3; the Lambert-only instance (waves of equal length) loses 2 % and keeps the barrier.
-        if (RT_SHADE_LAST_WAVE && FEAT != 0) {
-            const unsigned long long below0 = (1ull << lane) - 1ull;
-            if (r.emit_ext) s_stage[wave][0][__popcll(me & below0)] = os | (kRayExt << 30);
-            if (r.emit_sh) s_stage[wave][1][__popcll(ms & below0)] = os | (kRayShadow << 30);
-            if (r.emit_pr) s_stage[wave][2][__popcll(mp & below0)] = os | (kRayProbe << 30);
-            uint32_t n_part = 0;
-            for (uint32_t w = 0; w < kSW; w++) n_part += s_alive[w];
-            // release (every lane: all of them staged entries): this wave's s_stage / s_cnt writes are visible before it is
-            // counted; acquire: the last arriver reads the other waves' entries only after it has seen their counts.
-            // Workgroup scope, LDS address space only -- the wave's global stores need not have landed.
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-            uint32_t prev = 0;
-            if (lane == 0) prev = __hip_atomic_fetch_add(&s_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            prev = (uint32_t)__builtin_amdgcn_readfirstlane((int)prev);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-            RT_PROF(9)
-            if (prev + 1u < n_part) {
-                RT_PROF_FLUSH
-                return;
-            }
-            // last wave: totals, one reservation, all entries kind by kind ([ext of the waves][shadow ...][probe ...])
-            uint32_t cnt[3][kSW], tk[3] = {0, 0, 0}, tv = 0;
-            for (uint32_t w = 0; w < kSW; w++) {
-                const bool al = s_alive[w] != 0u;
-                for (uint32_t k = 0; k < 3; k++) {
-                    cnt[k][w] = al ? s_cnt[w][1 + k] : 0u;
-                    tk[k] += cnt[k][w];
-                }
-                tv += s_cnt[w][0];
-            }
-            const uint32_t tot = tk[0] + tk[1] + tk[2];
-            uint32_t qb = 0;
-            if (lane == 0) {
-                qb = tot ? atomicAdd(&ctl->n_rays[itn], tot) : 0u;
-                DevStats* sh = stat_shard(stats);
-                if (tk[0]) atomicAdd(&sh->r1, (unsigned long long)tk[0]);
-                if (tk[1]) atomicAdd(&sh->r2, (unsigned long long)tk[1]);
-                if (tk[2]) atomicAdd(&sh->r3, (unsigned long long)tk[2]);
-                if (tv) atomicAdd(&sh->vertices, (unsigned long long)tv);
-            }
-            qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
-            uint32_t o = qb;
-            for (uint32_t k = 0; k < 3; k++)
-                for (uint32_t w = 0; w < kSW; w++) {
-                    if (lane < cnt[k][w]) queue_out[o + lane] = s_stage[w][k][lane];
-                    o += cnt[k][w];
-                }
-            RT_PROF(9)
-            RT_PROF_FLUSH
-            return;
+        if (ms) {
+            const uint32_t at = cursor_take(cq1, c_rays, chunk, (uint32_t)__popcll(ms), (uint32_t)__popcll(ms & below));
+            if (r.emit_sh && at < q_cap) queue_out[at] = os | (kRayShadow << 30);
+            n_r2 += (uint32_t)__popcll(ms);
         }
-        __syncthreads();
-        if (leader) {
-            uint32_t te = 0, tsd = 0, tp = 0, tv = 0;
-            for (uint32_t w = 0; w < kSW; w++) {
-                te += s_cnt[w][1];
-                tsd += s_cnt[w][2];
-                tp += s_cnt[w][3];
-                tv += s_cnt[w][0];
-            }
-            const uint32_t tot = te + tsd + tp;
-            s_base[1] = tot ? atomicAdd(&ctl->n_rays[itn], tot) : 0u;
-            DevStats* sh = stat_shard(stats);
-            if (te) atomicAdd(&sh->r1, (unsigned long long)te);
-            if (tsd) atomicAdd(&sh->r2, (unsigned long long)tsd);
-            if (tp) atomicAdd(&sh->r3, (unsigned long long)tp);
-            if (tv) atomicAdd(&sh->vertices, (unsigned long long)tv);
+        if (mp) {
+            const uint32_t at = cursor_take(cq2, c_rays, chunk, (uint32_t)__popcll(mp), (uint32_t)__popcll(mp & below));
+            if (r.emit_pr && at < q_cap) queue_out[at] = os | (kRayProbe << 30);
+            n_r3 += (uint32_t)__popcll(mp);
         }
-        __syncthreads();
-        const unsigned long long below = (1ull << lane) - 1ull;
-#if RT_QUEUE_BY_KIND
-        // the block's rays kind by kind -- [extension of the 4 waves][shadow ...][probe ...] -- so that a traversal
-        // wave's 128-entry reservation is mostly one kind (shadow rays all run towards the light, probes and
-        // extensions anywhere): k_trace -0.6 % (C4) / -2.9 % (C3) / -2.6 % (C2) against wave-by-wave order
-        uint32_t oe = s_base[1], osd = 0, op = 0, te = 0, tsd = 0;
-        for (uint32_t w = 0; w < kSW; w++) {
-            if (w < wave) {
-                oe += s_cnt[w][1];
-                osd += s_cnt[w][2];
-                op += s_cnt[w][3];
-            }
-            te += s_cnt[w][1];
-            tsd += s_cnt[w][2];
+        if (mf) {
+            const uint32_t at = cursor_take(cf, c_fold, chunk, (uint32_t)__popcll(mf), (uint32_t)__popcll(mf & below));
+            if (r.keep && !r.emit_ext && at < lists.cap) fold_out[at] = os;
         }
-        osd += s_base[1] + te;
-        op += s_base[1] + te + tsd;
-        if (r.emit_ext) queue_out[oe + (uint32_t)__popcll(me & below)] = os | (kRayExt << 30);
-        if (r.emit_sh) queue_out[osd + (uint32_t)__popcll(ms & below)] = os | (kRayShadow << 30);
-        if (r.emit_pr) queue_out[op + (uint32_t)__popcll(mp & below)] = os | (kRayProbe << 30);
-        (void)cp;
-#else
-        uint32_t off = s_base[1];
-        for (uint32_t w = 0; w < wave; w++) off += s_cnt[w][1] + s_cnt[w][2] + s_cnt[w][3];
-        if (r.emit_ext) queue_out[off + (uint32_t)__popcll(me & below)] = os | (kRayExt << 30);
-        if (r.emit_sh) queue_out[off + ce + (uint32_t)__popcll(ms & below)] = os | (kRayShadow << 30);
-        if (r.emit_pr) queue_out[off + ce + cs + (uint32_t)__popcll(mp & below)] = os | (kRayProbe << 30);
-#endif
     }
-    RT_PROF(9)
-    RT_PROF_FLUSH
+    cursor_pad(cq0, queue_out, q_cap);
+    cursor_pad(cq1, queue_out, q_cap);
+    cursor_pad(cq2, queue_out, q_cap);
+    cursor_pad(cf, fold_out, lists.cap);
+    if (lane == 0) {
+        DevStats* sh = stat_shard(stats);
+        if (n_r1) atomicAdd(&sh->r1, (unsigned long long)n_r1);
+        if (n_r2) atomicAdd(&sh->r2, (unsigned long long)n_r2);
+        if (n_r3) atomicAdd(&sh->r3, (unsigned long long)n_r3);
+        if (n_v) atomicAdd(&sh->vertices, (unsigned long long)n_v);
+    }
+}
+
+// The paths that end this bounce without a vertex to shade: list 0 (the extension ray escaped) and the fold list (no
+// extension ray, only pending light terms).  Fold, emitted light of the environment, film staging -- a few dozen
+// registers and, for most of them, 48 of the record's 256 bytes.
+template <int FEAT>
+__global__ __launch_bounds__(256) void k_shade_light(DevScene sc, PathState in, Ctl* ctl, uint32_t it_abs, uint32_t max_depth,
+                                                     Lists lists, f64_t* lfx, f64_t* lfy, f64_t* lfz) {
+    const uint32_t n0 = ctl->cls_count[it_abs & 3u][0][0], n1 = ctl->fold_count[it_abs & 3u][0];
+    const uint32_t g0 = (n0 + 63u) / 64u, n_groups = g0 + (n1 + 63u) / 64u;
+    const uint32_t lane = threadIdx.x & 63u, n_waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t* fold_in = lists.fold[it_abs & 1u];
+    for (uint32_t g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); g < n_groups; g += n_waves) {
+        uint32_t slot = kNullEntry;
+        if (g < g0) {
+            const uint32_t i = g * 64u + lane;
+            if (i < n0) slot = lists.ent[i].slot;
+        } else {
+            const uint32_t i = (g - g0) * 64u + lane;
+            if (i < n1) slot = fold_in[i];
+        }
+        ShadeA a;
+        shade_a<FEAT, kKindNone>(sc, in, slot, 0u, false, slot != kNullEntry, max_depth, a);
+        if (a.live) {
+            const uint32_t og = a.orig;
+            lfx[og] = a.L.x;
+            lfy[og] = a.L.y;
+            lfz[og] = a.L.z;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------- tail
 // Once a lane's batch is exhausted and few paths are left, per-bounce launches are bound by the single
 // longest ray of each launch (a few hundred dependent fetches), times the remaining bounces.  k_tail
 // finishes those paths in ONE launch with the same closest_hit and the same shade_a / shade_b, ping-ponging a
-// path's slot between the two state buffers until it retires.  Same arithmetic, same counters, no queues.
-// Persistent waves with (a) path replacement: a lane whose path has retired takes the next unfinished path of the
-// list (one atomic per wave and refill), so a wave does not sit on a register allocation for the sake of its one
+// path's record between the two pools (same slot) until it retires.  Same arithmetic, same counters, no queues.
+// Its paths are the queue's extension entries plus the fold list of the iteration it replaces.
+// Persistent waves with (a) path replacement: a lane whose path has retired takes the next unfinished path
+// (one atomic per wave and refill), so a wave does not sit on a register allocation for the sake of its one
 // longest path; and (b) pooled rays: the pending rays of the wave's live paths (up to three each: shadow, probe,
 // extension) are listed in LDS and dealt to ALL 64 lanes, so a path's three rays are traced side by side.
-// The two state buffers alternate per bounce, wave-uniformly: new paths are taken on even passes only.
+// The two pools alternate per bounce, wave-uniformly: new paths are taken on even passes only.
 // COUNT: the instrumented build (RT_RENDER_COUNT_TRAVERSAL) also counts the tail's node / primitive tests; its rays
 // are always counted (rt_stats.tail_*), so that the traversal kernel's own share is known exactly.
 template <int FEAT, bool COUNT>
 __global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathState buf1, Ctl* ctl,
-                                             uint32_t it_abs, uint32_t max_depth, f64_t* lfx, f64_t* lfy,
-                                             f64_t* lfz, DevStats* stats) {
+                                             uint32_t it_abs, uint32_t max_depth, const uint32_t* __restrict__ queue,
+                                             Lists lists, f64_t* lfx, f64_t* lfy, f64_t* lfz, DevStats* stats) {
     __shared__ int2 lds_stack[kLdsStack * 256];
     __shared__ uint32_t s_job[4][192];  // per wave: slot of the path | ray kind << 30
-    __shared__ int2 s_res[4][192];      // per wave: {prim, leaf slot} found for job j
+    __shared__ int2 s_res[4][192];      // per wave: {prim, hit word} found for job j
     const uint32_t ring = it_abs % kRing;
-    const uint32_t n_active = ctl->n_active[ring];
+    const uint32_t n_q = ctl->n_rays[ring], n_total = n_q + ctl->fold_count[it_abs & 3u][0];
+    const uint32_t* fold_in = lists.fold[it_abs & 1u];
     uint32_t* next_path = &ctl->head[ring];  // zero at launch: no k_trace runs in the tail iteration (k_plan cleared it)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t slot = 0;
@@ -1064,21 +984,31 @@ __global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathS
                 if (lane == 0) base = atomicAdd(next_path, want);
                 base = __shfl(base, 0, 64);
                 const uint32_t idx = base + (uint32_t)__popcll(md & below);
-                if (!alive && idx < n_active) {
-                    slot = idx;
-                    alive = true;
+                if (!alive && idx < n_total) {
+                    // a path = an extension entry of the queue, or an entry of the fold list (shadow / probe entries and
+                    // the null ends of chunks are skipped: the lane asks again on the next even pass)
+                    uint32_t s = kNullEntry;
+                    if (idx < n_q) {
+                        const uint32_t e = queue[idx];
+                        if ((e >> 30) == kRayExt) s = e & kSlotMask;
+                    } else {
+                        s = fold_in[idx - n_q];
+                    }
+                    if (s != kNullEntry) {
+                        slot = s;
+                        alive = true;
+                    }
                 }
-                if (base + want >= n_active) list_done = true;
+                if (base + want >= n_total) list_done = true;
             }
         }
         // the state a path's owner lane wrote in the previous pass is read by other lanes of the wave below
         if (pass) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        uint32_t fl = kDead;
-        if (alive) fl = in.flags[slot];
-        if (fl & kDead) alive = false;
+        uint32_t fl = 0;
+        if (alive) fl = (uint32_t)(rec_words(in, slot)[kWMeta] >> 32);
         if (__ballot(alive) == 0ull) {
             if (list_done) break;
-            continue;  // (an odd pass with nothing alive: the next one refills)
+            continue;  // (nothing alive: the next even pass refills)
         }
         const bool has_sh = alive && (fl & kHasShadow), has_pr = alive && (fl & kHasProbe);
         const bool has_ex = alive && !(fl & kFoldOnly);
@@ -1097,37 +1027,36 @@ __global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathS
         for (uint32_t j = lane; j < n_jobs; j += 64u) {
             const uint32_t job = s_job[wave][j];
             const uint32_t js = job & kSlotMask, kind = job >> 30;
-            const D3 o = ld3(in.ox, in.oy, in.oz, js);
+            const rt_w* jr = rec_words(in, js);
+            const D3 o = ld3w<kWO>(jr);
             double t;
             uint32_t hs = 0;
             int32_t prim;
             if (kind == kRayShadow) {  // Visibility::unoccluded, hittable.rs:25-32
-                const D3 d = ld3(in.spx, in.spy, in.spz, js) - o;
+                const D3 d = ld3w<kWSp>(jr) - o;
                 prim = closest_hit<COUNT>(sc, o + d * kSmall, d, 0.0, kInf, t, ts, &tc);
             } else if (kind == kRayProbe) {
-                prim = closest_hit<COUNT>(sc, o, ld3(in.pdx, in.pdy, in.pdz, js), kSmall, kInf, t, ts, &tc);
+                prim = closest_hit<COUNT>(sc, o, ld3w<kWPd>(jr), kSmall, kInf, t, ts, &tc);
             } else {
-                prim = closest_hit<COUNT>(sc, o, ld3(in.dx, in.dy, in.dz, js), kSmall, kInf, t, ts, &tc, &hs);
+                prim = closest_hit<COUNT>(sc, o, ld3w<kWD>(jr), kSmall, kInf, t, ts, &tc, &hs);
             }
-            s_res[wave][j] = make_int2(prim, (int)hs);
+            s_res[wave][j] = make_int2(prim, prim < 0 ? 0 : (int)hit_word(prim, hs));
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (has_sh) in.sh_prim[slot] = s_res[wave][jsh].x;
-        if (has_pr) in.pr_prim[slot] = s_res[wave][jpr].x;
-        if (has_ex) {
-            const int2 r = s_res[wave][jex];
-            in.hit_prim[slot] = r.x;
-            in.hit_slot[slot] = (uint32_t)r.y;
-        }
         if (alive) {
+            int32_t* res = reinterpret_cast<int32_t*>(rec_words(in, slot) + kWRes);
+            if (has_sh) res[0] = s_res[wave][jsh].x;
+            if (has_pr) res[1] = s_res[wave][jpr].x;
+            asm volatile("" ::: "memory");  // shade_a reads these words back through another pointer type
+            int2 hr = make_int2(-1, 0);
+            if (has_ex) hr = s_res[wave][jex];
             ShadeA a;
-            RT_PROF_DECL
-            shade_a<FEAT>(sc, in, slot, true, max_depth, a RT_PROF_PASS);
+            shade_a<FEAT, kKindAny>(sc, in, slot, (uint32_t)hr.y, hr.x >= 0, true, max_depth, a);
             ShadeOut r{false, false, false, false};
             if (a.will_shade) {
-                r = shade_b<FEAT>(sc, in, out, slot, slot, a RT_PROF_PASS);
+                r = shade_b<FEAT>(sc, out, slot, a);
                 n_v++;
             }
             n_r1 += r.emit_ext ? 1u : 0u;
@@ -1158,7 +1087,7 @@ __global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathS
     }
 }
 
-#ifndef RT_F32  // the film is f64 in both modes: compiled once
+#if defined(RT_KERNELS_CORE) && !defined(RT_F32)  // the film is f64 in both modes: compiled once
 // ------------------------------------------------------------------- resolve
 // util::increment_color order: each pixel's samples are added one by one, in sample order.
 __global__ __launch_bounds__(256) void k_resolve(const double* __restrict__ lfx, const double* __restrict__ lfy,

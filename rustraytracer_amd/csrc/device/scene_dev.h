@@ -26,7 +26,7 @@ static_assert(sizeof(DevNode) == 128, "DevNode must be 128 bytes");
 constexpr int32_t kNoChild = INT32_MIN;
 constexpr uint32_t kLeafOther = 0x80000000u;  // leaf entry is a sphere/rect, not a triangle
 constexpr uint32_t kLeafCodeOther = 1u << 30;
-constexpr uint64_t kMaxPrims = 1ull << 27;  // exclusive: leaf slots occupy bits 3..29 of a leaf code
+constexpr uint64_t kMaxPrims = 1ull << 27;  // exclusive: leaf slots occupy bits 3..29 of a leaf code, bits 0..26 of a hit word
 constexpr uint32_t kMetaHasNormals = 1u << 30, kMetaFlip = 1u << 31, kMetaMatMask = 0x3fffffffu;  // leaf code flag: the leaf holds one sphere/rect (they never share a leaf)
 constexpr int kMaxLeafPrims = 4;     // what a leaf code can hold
 // What the builders aim for.  One primitive per leaf: the parent's f32 test of the child box then culls each
@@ -73,7 +73,7 @@ struct DevEnv {
 
 struct DevScene {
     const DevNode* nodes;
-    const uint32_t* leaf_prim;  // leaf order -> prim index | kLeafOther
+    const uint32_t* leaf_prim;  // leaf order -> prim index | vertex class << kClsShift | kLeafOther
     const double* leaf_tri;     // leaf order -> 9 doubles p0,p1,p2 (triangles), 72 B
     // The traversal kernel's own copy of a leaf slot, one aligned 128-B line (16 doubles) per slot, so that a primitive
     // test touches ONE cache line instead of 2.4 (a 72-B record straddles lines 7 times in 16, the primitive index
@@ -108,40 +108,63 @@ struct DevScene {
 };
 
 // ----------------------------------------------------------------- path state
-// SoA over path slots.  One slot = one camera sample of the current chunk.
-// Two such buffers ping-pong per bounce (see kernels.hip).  Bytes per slot: 9 vec3 * 24 = 216
-// (o d sp pd beta L A B bk) + 8 rng + 12 prim results + 4 flags + 4 orig = 244.
+// One RECORD of 256 B per path slot = two 128-B cache lines = four 64-B HBM atoms (round 4; rounds 1-3 kept 34 separate
+// arrays).  A lane's whole state costs the two lines it costs anyway, in WHATEVER order the slots are visited -- which is
+// what lets the shading kernels run on class-pure waves gathered over the whole launch (kernels.hip: the class lists):
+// with separate arrays a gathered wave touched 13-27 lines per load instead of 4.
+// Fields are addressed in 8-byte words (a vec3 is three consecutive words); the fast mode keeps its binary32 values in
+// the low half of each word.  Two such pools ping-pong per bounce (kernels.hip).
+//   atom 0  w0-2 o   w3-5 d   w6 rng   w7 {orig, flags}          camera sample / extension ray: ONE atom
+//   atom 1  w8-10 sp   w11-13 beta   w14 {sh_prim, pr_prim}   w15 {hit_prim, hit word}  (w15: k_tail / rt_intersect_batch only)
+//   atom 2  w16-18 L   w19-21 A   w22-23 Q.xy
+//   atom 3  w24 Q.z   w25-27 K   w28-30 pd   w31 spare
+// o = ray origin (last hit point; spawn_ray adds no offset), d = extension direction, sp = sampled light point (shadow
+// ray target), pd = MIS probe direction, A / Q = pending light-sample / bsdf-sample terms (f * Le * w / pdf), K = beta at
+// the vertex that produced them, orig = film staging slot (sample_local * n_pixels + pixel_local).
 struct PathState {
-    double *ox, *oy, *oz;     // ray origin = last hit point (spawn_ray: no offset)
-    double *dx, *dy, *dz;     // extension direction
-    double *spx, *spy, *spz;  // sampled light point (shadow ray target)
-    double *pdx, *pdy, *pdz;  // MIS probe direction
-    double *bx, *by, *bz;     // beta
-    double *lx, *ly, *lz;     // L
-    double *ax, *ay, *az;     // pending light-sample term  (f*Le*w/pdf)
-    double *qx, *qy, *qz;     // pending bsdf-sample term   (f*Le*w/pdf)
-    double *kx, *ky, *kz;     // beta at the vertex that produced the pending terms
-    uint64_t* rng;
-    int32_t* hit_prim;        // result of the extension ray
-    uint32_t* hit_slot;       // leaf slot of that hit (| kLeafOther for a sphere / rect)
-    int32_t* sh_prim;         // closest prim along the shadow ray (Q13)
-    int32_t* pr_prim;         // closest prim along the probe ray
-    uint32_t* flags;
-    uint32_t* orig;           // film staging slot of this path: sample_local * n_pixels + pixel_local
+    char* rec;
 };
+constexpr uint32_t kRecBytes = 256;
+constexpr int kWO = 0, kWD = 3, kWRng = 6, kWMeta = 7, kWSp = 8, kWBeta = 11, kWRes = 14, kWHit = 15, kWL = 16, kWA = 19, kWQ = 22,
+              kWK = 25, kWPd = 28;
 // flags
 constexpr uint32_t kBounceMask = 0xffu;
 constexpr uint32_t kSpecular = 1u << 8;
 constexpr uint32_t kFoldOnly = 1u << 9;
 constexpr uint32_t kHasShadow = 1u << 10;
 constexpr uint32_t kHasProbe = 1u << 11;
-constexpr uint32_t kDead = 1u << 12;  // slot allocated for a vertex whose path then ended with nothing pending
 constexpr uint32_t kFresh = 1u << 13;  // a camera sample k_generate has just written: beta = 1, L = 0 are implied, not stored
 constexpr uint32_t kLightShift = 16;
 
-// queue entry = slot | kind << 30
-constexpr uint32_t kRayExt = 0u, kRayShadow = 1u, kRayProbe = 2u;
+// queue entry = slot | kind << 30; kRayNone fills the unused end of a wave's queue chunk
+constexpr uint32_t kRayExt = 0u, kRayShadow = 1u, kRayProbe = 2u, kRayNone = 3u;
 constexpr uint32_t kSlotMask = 0x3fffffffu;
+constexpr uint32_t kNullEntry = 0xffffffffu;  // unused queue / list entry
+
+// ---- vertex classes (round 4).  Every primitive belongs to a class = (smallest shading-kernel instance that covers its
+// material, kind of hit record: mesh slot / sphere-rect / generic); class 0 = the extension ray escaped.  A leaf's class
+// rides in bits 27-30 of its leaf_prim word (and so in the traversal's best_slot), the traversal kernel appends every
+// finished extension ray to the list of its class, and one shading kernel per class runs on waves that are class-pure
+// over the whole launch.
+constexpr int kMaxCls = 16;
+constexpr uint32_t kClsShift = 27;
+constexpr uint32_t kIdxMask = (1u << kClsShift) - 1u;  // leaf slot / primitive index part of a leaf_prim or hit word
+// hit word of a list entry: class bits, kLeafOther, and the LEAF SLOT of a mesh hit or the PRIMITIVE INDEX of a sphere /
+// rect hit -- what the record of that kind of hit is rebuilt from (geom.h: tri_record_slot / prim_intersects)
+constexpr int kKindAny = 0, kKindMesh = 1, kKindOther = 2, kKindNone = 3;
+struct ClsDesc {
+    uint8_t variant;  // index into kFeatVariants
+    uint8_t kind;     // kKind*
+};
+struct alignas(8) ListEnt {
+    uint32_t slot, hit;
+};
+struct Lists {
+    ListEnt* ent;      // [n_cls][cap]: {slot, hit word}; class c at ent + c * cap
+    uint32_t* fold[2];  // slots of fold-only paths, written by the shading kernels of iteration it for it + 1
+    uint32_t cap;      // entries per list
+    uint32_t n_cls;
+};
 
 struct DevStats {  // one shard = two 64-B lines; kStatShards shards, summed by the host
     unsigned long long paths, r1, r2, r3, vertices, nodes, tris, others;
@@ -161,6 +184,9 @@ struct Ctl {
     uint32_t gen_count, gen_first, gen_slot, gen_q;
     // (RT_XCD_QUEUE) one queue head per XCD and iteration (ring of 4), each on its own 128-B line
     uint32_t xhead[4][8][32];
+    // lengths of the class lists / the fold list of an iteration (ring of 4), each counter on its own 128-B line
+    uint32_t cls_count[4][kMaxCls][32];
+    uint32_t fold_count[4][32];
 };
 
 // The batch being rendered, shared by both lanes.

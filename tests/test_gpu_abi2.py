@@ -435,7 +435,10 @@ except Exception as e:
     want = "film %s %d" % (hashlib.sha256(r.tobytes() + n.tobytes()).hexdigest(), st.rays)
 
     def child(pif):
-        env = dict(os.environ, RT_TEST_POOL_OOM_ABOVE="15")  # pools above 32768 paths "do not fit"
+        # (the hook exists in librt_amd_testhooks.so only -- csrc/Makefile `testhooks`; the product library ignores the variable)
+        hooks = os.path.join(root, "rustraytracer_amd", "librt_amd_testhooks.so")
+        assert os.path.exists(hooks), "build it with: make -C rustraytracer_amd/csrc testhooks"
+        env = dict(os.environ, RT_TEST_POOL_OOM_ABOVE="15", RT_AMD_LIB=hooks)  # pools above 32768 paths "do not fit"
         out = subprocess.run([sys.executable, "-c", code, str(pif)], env=env, capture_output=True, text=True, timeout=300)
         lines = [ln for ln in out.stdout.splitlines() if ln.startswith(("film", "error"))]
         assert lines, out.stderr[-800:]

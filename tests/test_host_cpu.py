@@ -77,11 +77,16 @@ def test_library_exports_every_declared_symbol():
     # the shared object really contains gfx950 code
     blob = open(F.LIB_PATH, "rb").read()
     assert b"amdgcn-amd-amdhsa--gfx950" in blob
-    # every kernel instance the launch tables of abi.hip can pick is in the library: the six shading / tail
-    # instances (feature masks of shading.h: kFeatVariants), the traversal kernel with and without counters / simple leaves
-    for feat in (0, 1, 2, 3, 7, 19, 23, 15, 31):
-        assert b"_ZN3rtd7k_shadeILi%dEEE" % feat in blob
-        assert b"_ZN3rtd6k_tailILi%dELb0EEE" % feat in blob and b"_ZN3rtd6k_tailILi%dELb1EEE" % feat in blob
+    # every kernel instance the launch tables of abi.hip can pick is in the library: the class kernels (three kinds of hit
+    # record) and the fused tail of the nine shading-feature masks (shading.h: kFeatVariants) in both precisions, the
+    # light kernel with and without the environment, the traversal kernel with and without counters / simple leaves
+    for ns in (b"3rtd", b"5rtd32"):
+        for feat in (0, 1, 2, 3, 7, 19, 23, 15, 31):
+            for kind in (0, 1, 2):
+                assert b"_ZN%s11k_shade_clsILi%dELi%dEEE" % (ns, feat, kind) in blob, (ns, feat, kind)
+            assert b"_ZN%s6k_tailILi%dELb0EEE" % (ns, feat) in blob and b"_ZN%s6k_tailILi%dELb1EEE" % (ns, feat) in blob
+        for env in (0, 16):
+            assert b"_ZN%s13k_shade_lightILi%dEEE" % (ns, env) in blob
     for inst in (b"k_traceILb0ELb0E", b"k_traceILb0ELb1E", b"k_traceILb1ELb0E", b"k_intersect_batch", b"k_generate",
                  b"k_resolve", b"k_tonemap", b"kb_scatter", b"kb_emit", b"k_film_pack", b"k_film_unpack"):
         assert inst in blob, inst
