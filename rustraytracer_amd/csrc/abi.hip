@@ -88,7 +88,7 @@ struct rt_context {
     int n_lanes = 1;  // RT_LANES=2 runs two pools concurrently (same throughput once the pool is large)
     DevStats* stats = nullptr;
     BatchCtl* batch = nullptr;
-    double* lf[3] = {nullptr, nullptr, nullptr};  // film staging of the current batch: radiance of retired paths
+    double* lf = nullptr;  // film staging of the current batch: the radiance of retired paths, 3 doubles per camera sample
     size_t lf_capacity = 0;
     uint32_t* pix_list = nullptr;
     size_t pix_capacity = 0;
@@ -314,7 +314,7 @@ int rt_context_destroy(rt_context* c) {
     }
     if (c->stats) (void)hipFree(c->stats);
     if (c->batch) (void)hipFree(c->batch);
-    if (c->lf[0]) (void)hipFree(c->lf[0]);
+    if (c->lf) (void)hipFree(c->lf);
     if (c->pix_list) (void)hipFree(c->pix_list);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1172,8 +1172,7 @@ static int run_lane(RenderJob& job, int lane_id) {
                     // that are each as slow as their single longest ray
                                         const uint32_t tail_blocks = std::min((live + 255) / 256, (uint32_t)c->num_cus * 2u);  // persistent waves
                     hipLaunchKernelGGL(tail_kernel(job.s->shade_variant, job.count_trav, job.f32_tail), dim3(tail_blocks), dim3(256), 0, stream, job.s->dev, ln.st[0],
-                                       ln.st[1], ln.ctl, (uint32_t)it, cfg->max_depth, ln.queue[it & 1], ln.lists, c->lf[0], c->lf[1],
-                                       c->lf[2], c->stats);
+                                       ln.st[1], ln.ctl, (uint32_t)it, cfg->max_depth, ln.queue[it & 1], ln.lists, c->lf, c->stats);
                     break;
                 }
             }
@@ -1210,9 +1209,9 @@ static int run_lane(RenderJob& job, int lane_id) {
         for (uint32_t k = 1; k < job.s->n_cls; k++)
             hipLaunchKernelGGL(shade_cls_kernel(job.s->cls[k], job.f32_shade), dim3(std::min(shade_want, (uint32_t)job.shade_blocks[k])), dim3(256), 0,
                                stream, job.s->dev, ln.st[it & 1], ln.st[(it + 1) & 1], ln.ctl, (uint32_t)it, cfg->max_depth, ln.lists, k,
-                               ln.queue[(it + 1) & 1], ln.q_cap, ln.slot_cap, c->lf[0], c->lf[1], c->lf[2], c->stats);
+                               ln.queue[(it + 1) & 1], ln.q_cap, ln.slot_cap, c->lf, c->stats);
         hipLaunchKernelGGL(shade_light_kernel(job.s->dev.env.light >= 0, job.f32_shade), dim3(std::min(shade_want, (uint32_t)job.shade_blocks[0])), dim3(256),
-                           0, stream, job.s->dev, ln.st[it & 1], ln.ctl, (uint32_t)it, cfg->max_depth, ln.lists, c->lf[0], c->lf[1], c->lf[2]);
+                           0, stream, job.s->dev, ln.st[it & 1], ln.ctl, (uint32_t)it, cfg->max_depth, ln.lists, c->lf);
         if (!no_ev) {  // the shading kernel runs from event b (end of k_trace) to this one
             hipEvent_t e = get_event(ln.events, ln.ev_i++);
             if (!e) {
@@ -1315,12 +1314,10 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
         // pool per lane
         // (the film staging first: what the pool's default may take is what is left after it)
         if (c->lf_capacity < batch_cap) {
-            if (c->lf[0]) HIP_TRY(hipFree(c->lf[0]));
-            c->lf[0] = c->lf[1] = c->lf[2] = nullptr;
+            if (c->lf) HIP_TRY(hipFree(c->lf));
+            c->lf = nullptr;
             c->lf_capacity = 0;
-            HIP_TRY(hipMalloc((void**)&c->lf[0], batch_cap * 3 * sizeof(double)));
-            c->lf[1] = c->lf[0] + batch_cap;
-            c->lf[2] = c->lf[1] + batch_cap;
+            HIP_TRY(hipMalloc((void**)&c->lf, batch_cap * 3 * sizeof(double)));
             c->lf_capacity = batch_cap;
         }
         // default pool: 256 Mi paths = a whole batch (140 GB of path state of the 288 GB when a batch is that large; smaller
@@ -1427,7 +1424,7 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
                     }
                 }
                 // every lane has drained (run_lane synchronises its stream): add the batch to the film
-                hipLaunchKernelGGL(rtk::kernel_table().resolve, dim3((npx + 255) / 256), dim3(256), 0, stream, c->lf[0], c->lf[1], c->lf[2],
+                hipLaunchKernelGGL(rtk::kernel_table().resolve, dim3((npx + 255) / 256), dim3(256), 0, stream, c->lf,
                                    ck, c->pix_list, d_rgb, d_n);
                 HIP_TRY(hipGetLastError());
             }

@@ -83,6 +83,26 @@ RTD void st_meta(rt_w* r, uint64_t rng, uint32_t orig, uint32_t flags) {
     q.y = (rt_w)orig | ((rt_w)flags << 32);
     *reinterpret_cast<rt_w2*>(r + kWRng) = q;
 }
+// film staging: the radiance of a retired path, three consecutive doubles at its (pixel, sample) slot (one partly written
+// HBM atom per path; rounds 1-3 had three arrays, whose writes came in path order -- the class lists scramble it)
+RTD void film_put(f64_t* lf, uint32_t og, D3 v) {
+    f64_t* q = lf + (size_t)og * 3;
+    q[0] = v.x;
+    q[1] = v.y;
+    q[2] = v.z;
+}
+// w8-15: beta, L and the zeroed result words
+RTD void st_beta_l(rt_w* r, D3 beta, D3 l) {
+    rt_w2 q;
+    q.x = r2w(beta.x); q.y = r2w(beta.y);
+    *reinterpret_cast<rt_w2*>(r + 8) = q;
+    q.x = r2w(beta.z); q.y = r2w(l.x);
+    *reinterpret_cast<rt_w2*>(r + 10) = q;
+    q.x = r2w(l.y); q.y = r2w(l.z);
+    *reinterpret_cast<rt_w2*>(r + 12) = q;
+    q.x = 0ull; q.y = 0ull;
+    *reinterpret_cast<rt_w2*>(r + 14) = q;
+}
 // a record's pairs in registers (the fields a kernel wants are fetched up front, independent of each other)
 struct RecRegs {
     rt_w2 p[16];
@@ -212,12 +232,12 @@ __global__ __launch_bounds__(256) void k_generate(PathState st, rt_camera cam, C
     const D3 to = ulc + ho * u - vo * v;
     const D3 dir = to - origin;
     (void)rng_next(rng);  // rand_range(t0, t1)
-    // one whole 64-B atom of the record: o, d, rng, {orig, flags}.  beta = 1 and L = 0 are not written: kFresh tells
-    // shade_a (the kernel is bound by its HBM writes)
+    // line 0 of the record in full (eight 16-B stores, no partly written atom): o, d, rng, {orig, flags}, beta = 1, L = 0
     rt_w* r = rec_words(st, slot);
     st3w<kWO>(r, origin + offset);
     st3w<kWD>(r, dir - offset);
-    st_meta(r, rng, g, kFresh);
+    st_meta(r, rng, g, 0u);
+    st_beta_l(r, white(), black());
     queue[ctl->gen_q + idx] = slot | (kRayExt << 30);
 }
 #endif  // RT_KERNELS_CORE
@@ -255,7 +275,8 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
         mirror[it].remaining = rem > 0xffffffffull ? 0xffffffffu : (uint32_t)rem;
         __hip_atomic_store(&mirror[it].seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // (the wave's number made wave-uniform for the compiler too: what is indexed / looped with it then lives in SGPRs)
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t n_waves = gridDim.x * 4u;
     uint32_t* const cls_counters = &ctl->cls_count[it_abs & 3u][0][0];
     const uint32_t list_chunk = pick_chunk(n, n_waves);
@@ -269,7 +290,7 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
                 const unsigned long long m = __ballot(ext);
                 if (m) {
                     const uint32_t at = wave_atomic_add(cls_counters, (uint32_t)__popcll(m)) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    if (ext && at < lists.cap) lists.ent[at] = ListEnt{slot, 0u};
+                    if (ext && at < lists.cap) lists.ent[at] = ListEnt{slot | ((e & kQPending) ? kEntPending : 0u), 0u};
                 }
             } else if (ext) {
                 reinterpret_cast<int32_t*>(rec_words(st, slot) + kWHit)[0] = -1;
@@ -359,7 +380,8 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
                         s_cls[wave][c][0] = cu.cur;
                         s_cls[wave][c][1] = cu.end;
                     }
-                    if (mine && at < lists.cap) lists.ent[(size_t)c * lists.cap + at] = ListEnt{slot, hw};
+                    if (mine && at < lists.cap)
+                        lists.ent[(size_t)c * lists.cap + at] = ListEnt{slot | ((slot_kind & kQPending) ? kEntPending : 0u), hw};
                 }
             } else if (wb_ext) {
                 int2 h;
@@ -553,30 +575,37 @@ struct ShadeA {
 };
 
 // `hit` = the extension ray's hit word (scene_dev.h), `some` = it hit something; both ignored for a fold-only path.
+// `pending` = the path may carry pending light terms (its flags decide): line 1 of its record is fetched as well.
 template <int FEAT, int KIND>
-RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, uint32_t hit, bool some, bool valid, uint32_t max_depth,
-                 ShadeA& a) {
-    // Every field of the record this function may need is fetched up front, unconditionally: the loads are
-    // independent, so they cost one memory latency instead of one per branch level below.  (A lane without a path reads
-    // record 0, which always exists.)  kKindNone -- escaped and fold-only paths, most of which need L and the film slot
-    // only -- fetches those first and the pending-light block on demand.
+RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, uint32_t hit, bool some, bool pending, bool valid,
+                 uint32_t max_depth, ShadeA& a) {
+    // Every field of the record this function may need is fetched up front: the loads are independent, so they cost one
+    // memory latency instead of one per branch level below.  (A lane without a path reads record 0, which always
+    // exists.)  Line 0 always (kKindNone, without an environment: its second atom and the flags only); line 1 -- the
+    // pending direct-light terms -- only for paths whose list entry says they may carry any.
     const rt_w* r = rec_words(in, valid ? slot : 0u);
     const rt_w2* rp = reinterpret_cast<const rt_w2*>(r);
     RecRegs R;
     R.p[3] = rp[3];
-    R.p[8] = rp[8];
-    R.p[9] = rp[9];
-    if (KIND != kKindNone) {
+    R.p[4] = rp[4];
+    R.p[5] = rp[5];
+    R.p[6] = rp[6];
+    R.p[7] = rp[7];
+    if (KIND != kKindNone || ((FEAT & kFeatEnv) != 0)) {
         R.p[0] = rp[0];
         R.p[1] = rp[1];
         R.p[2] = rp[2];
-        R.p[5] = rp[5];
-        R.p[6] = rp[6];
-        R.p[7] = rp[7];
+    }
+    if (pending) {
+        if (KIND == kKindNone && !((FEAT & kFeatEnv) != 0)) {  // (the probe fold starts at o)
+            R.p[0] = rp[0];
+            R.p[1] = rp[1];
+        }
+        R.p[8] = rp[8];
+        R.p[9] = rp[9];
         R.p[10] = rp[10];
         R.p[11] = rp[11];
         R.p[12] = rp[12];
-        R.p[13] = rp[13];
     }
     a.rng = R.p[3].x;
     a.orig = (uint32_t)R.p[3].y;
@@ -585,27 +614,10 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, uint32_
     a.live = valid;
     a.L = black();
     a.o = black();
-    if (KIND == kKindNone) {
-        if (valid && (fl & (kHasShadow | kHasProbe))) {
-            R.p[0] = rp[0];
-            R.p[1] = rp[1];
-            R.p[7] = rp[7];
-            R.p[10] = rp[10];
-            R.p[11] = rp[11];
-            R.p[12] = rp[12];
-            R.p[13] = rp[13];
-        }
-        if (((FEAT & kFeatEnv) != 0) && valid && !(fl & kFoldOnly)) {  // an escaped ray sees the environment
-            R.p[1] = rp[1];
-            R.p[2] = rp[2];
-            R.p[5] = rp[5];
-            R.p[6] = rp[6];
-        }
-    }
     if (a.live) {
-        a.L = (fl & kFresh) ? black() : rec3<kWL>(R);
+        a.L = rec3<kWL>(R);
         // ---- fold the previous vertex's direct lighting
-        if (fl & (kHasShadow | kHasProbe)) {
+        if (pending && (fl & (kHasShadow | kHasProbe))) {
             a.o = rec3<kWO>(R);
             const uint32_t light_idx = fl >> kLightShift;
             const rt_light& lt = sc.lights[light_idx];
@@ -631,15 +643,15 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, uint32_
                             // axis-aligned rect emitter: the record's normal faces the ray (set_front), so
                             // dot(n, -wi) = |wi's component along the rect's axis| and Light::l sees the colour
                             // unless that component is zero -- no need to build the record
-                            double t, ra, rb;
-                            D3 to, td;
+                            double t = 0.0, ra = 0.0, rb = 0.0;
+                            D3 to = black(), td = black();
                             if (rect_core(sc, lpr, a.o, pd, kSmall, kInf, t, ra, rb, to, td)) {
                                 const rt_light& lt2 = sc.lights[li];
                                 const bool lit = lt2.two_sided || absd(rect_axis_comp(lpr.kind, pd)) > 0.0;
                                 if (lit && !is_black(d3(lt2.color[0], lt2.color[1], lt2.color[2]))) ld = ld + q_in;
                             }
                         } else {
-                            HitRec nh;
+                            HitRec nh{};
                             if (prim_intersects(sc, pp, a.o, pd, kSmall, kInf, nh)) {
                                 const D3 col = light_l(sc.lights[li], nh.n, -pd);  // new_record.le(-wi)
                                 if (!is_black(col)) ld = ld + q_in;
@@ -662,7 +674,7 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, uint32_
         if (KIND != kKindNone || ((FEAT & kFeatEnv) != 0)) {
             if (KIND != kKindNone) a.o = rec3<kWO>(R);
             a.d = rec3<kWD>(R);
-            a.beta = (fl & kFresh) ? white() : rec3<kWBeta>(R);
+            a.beta = rec3<kWBeta>(R);
         }
         is_some = KIND != kKindNone && some;
         if (is_some) is_some = hit_record<KIND>(sc, hit, a.o, a.d, kSmall, kInf, a.rec);
@@ -692,7 +704,10 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& out, uint32_t os, Shad
     bool spec = a.spec;
     uint64_t rng = a.rng;
     rt_w* ow = rec_words(out, os);
-    Bsdf bsdf;
+    // (locals are initialised even where every path that reads them assigns them first: inside the class kernels' loop an
+    // undefined value is a register that stays allocated around the whole loop -- k_shade_cls<0, mesh> spilled 72 VGPRs
+    // with `ShadeA a;` and 7 with `ShadeA a{};`)
+    Bsdf bsdf{};
     compute_scattering<FEAT>(sc, rec, bsdf);
     bool has_sh = false, has_pr = false;
     uint32_t light_num = 0;
@@ -708,9 +723,9 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& out, uint32_t os, Shad
         const rt_primitive& lp = sc.light_prims[light_num];  // = prims[lt.prim_index] (zeros for the infinite light, unused)
         const uint32_t nsf = RT_BSDF_ALL - RT_BSDF_SPECULAR;
         const D3 ltcolor = d3(lt.color[0], lt.color[1], lt.color[2]);
-        D3 sp, sn;
-        double light_pdf;
-        D3 wi, color;
+        D3 sp = black(), sn = black();
+        double light_pdf = 0.0;
+        D3 wi = black(), color = black();
         if (infinite) {
             infinite_sample_li(sc, lt, rec.p, ul0, ul1, wi, light_pdf, color, sp);
         } else {
@@ -794,15 +809,13 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& out, uint32_t os, Shad
     r.emit_pr = has_pr;
     r.keep = cont || has_sh || has_pr;
     if (r.keep) {
+        // line 0 of the record in full (a fold-only path's d / beta are never read)
         st3w<kWO>(ow, rec.p);  // spawn_ray: origin = hit point (Q4)
-        st3w<kWL>(ow, a.L);
-        if (cont) {
-            st3w<kWD>(ow, wi);
-            st3w<kWBeta>(ow, beta);
-        }
+        st3w<kWD>(ow, wi);
         st_meta(ow, rng, a.orig,
                 (bounces & kBounceMask) | (spec ? kSpecular : 0u) | (cont ? 0u : kFoldOnly) | (has_sh ? kHasShadow : 0u) |
                     (has_pr ? kHasProbe : 0u) | (light_num << kLightShift));
+        st_beta_l(ow, beta, a.L);
     }
     return r;
 }
@@ -835,12 +848,14 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& out, uint32_t os, Shad
 template <int FEAT, int KIND>
 __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade_cls(DevScene sc, PathState in, PathState out, Ctl* ctl, uint32_t it_abs,
                                                uint32_t max_depth, Lists lists, uint32_t cls, uint32_t* queue_out, uint32_t q_cap,
-                                               uint32_t slot_cap, f64_t* lfx, f64_t* lfy, f64_t* lfz, DevStats* stats) {
+                                               uint32_t slot_cap, f64_t* lf, DevStats* stats) {
     const uint32_t itn = (it_abs + 1) % kRing;
     const uint32_t n = ctl->cls_count[it_abs & 3u][cls][0];
     const uint32_t n_groups = (n + 63u) / 64u;
     const uint32_t lane = threadIdx.x & 63u, n_waves = gridDim.x * (blockDim.x >> 6);
-    const uint32_t wave_g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // (wave-uniform for the compiler too: the loop below and its cursors then live in SGPRs -- with a per-lane loop counter
+    // every cursor is a VGPR and the kernel spills 76-139 registers instead of 8-16)
+    const uint32_t wave_g = blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (wave_g >= n_groups) return;
     const uint32_t chunk = pick_chunk(n, n_waves < n_groups ? n_waves : n_groups);
     const ListEnt* ent = lists.ent + (size_t)cls * lists.cap;
@@ -856,8 +871,8 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade_cls(DevScen
         ListEnt e{kNullEntry, 0u};
         if (i < n) e = ent[i];
         const bool valid = e.slot != kNullEntry;  // (null: the unused end of a traversal wave's list chunk)
-        ShadeA a;
-        shade_a<FEAT, KIND>(sc, in, e.slot, e.hit, true, valid, max_depth, a);
+        ShadeA a{};
+        shade_a<FEAT, KIND>(sc, in, e.slot & kSlotMask, e.hit, true, valid && (e.slot & kEntPending), valid, max_depth, a);
         const unsigned long long m = __ballot(a.will_shade);
         uint32_t os = 0;
         if (m) {
@@ -866,18 +881,13 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade_cls(DevScen
         }
         ShadeOut r{false, false, false, false};
         if (a.will_shade && os < slot_cap) r = shade_b<FEAT>(sc, out, os, a);
-        if (a.live && !r.keep) {  // retired: its radiance goes to the film staging slot of (pixel, sample)
-            const uint32_t og = a.orig;
-            lfx[og] = a.L.x;
-            lfy[og] = a.L.y;
-            lfz[og] = a.L.z;
-        }
+        if (a.live && !r.keep) film_put(lf, a.orig, a.L);  // retired: its radiance goes to the film staging slot of (pixel, sample)
         // ---- rays of the next bounce, and the paths that only have light terms to fold
         const unsigned long long me = __ballot(r.emit_ext), ms = __ballot(r.emit_sh), mp = __ballot(r.emit_pr);
         const unsigned long long mf = __ballot(r.keep && !r.emit_ext);
         if (me) {
             const uint32_t at = cursor_take(cq0, c_rays, chunk, (uint32_t)__popcll(me), (uint32_t)__popcll(me & below));
-            if (r.emit_ext && at < q_cap) queue_out[at] = os | (kRayExt << 30);
+            if (r.emit_ext && at < q_cap) queue_out[at] = os | ((r.emit_sh || r.emit_pr) ? kQPending : 0u) | (kRayExt << 30);
             n_r1 += (uint32_t)__popcll(me);
         }
         if (ms) {
@@ -913,28 +923,26 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade_cls(DevScen
 // registers and, for most of them, 48 of the record's 256 bytes.
 template <int FEAT>
 __global__ __launch_bounds__(256) void k_shade_light(DevScene sc, PathState in, Ctl* ctl, uint32_t it_abs, uint32_t max_depth,
-                                                     Lists lists, f64_t* lfx, f64_t* lfy, f64_t* lfz) {
+                                                     Lists lists, f64_t* lf) {
     const uint32_t n0 = ctl->cls_count[it_abs & 3u][0][0], n1 = ctl->fold_count[it_abs & 3u][0];
     const uint32_t g0 = (n0 + 63u) / 64u, n_groups = g0 + (n1 + 63u) / 64u;
     const uint32_t lane = threadIdx.x & 63u, n_waves = gridDim.x * (blockDim.x >> 6);
     const uint32_t* fold_in = lists.fold[it_abs & 1u];
-    for (uint32_t g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); g < n_groups; g += n_waves) {
+    for (uint32_t g = blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); g < n_groups; g += n_waves) {
         uint32_t slot = kNullEntry;
+        bool pending = true;  // a fold-only path is nothing but pending terms
         if (g < g0) {
             const uint32_t i = g * 64u + lane;
             if (i < n0) slot = lists.ent[i].slot;
+            pending = (slot & kEntPending) != 0u;
         } else {
             const uint32_t i = (g - g0) * 64u + lane;
             if (i < n1) slot = fold_in[i];
         }
-        ShadeA a;
-        shade_a<FEAT, kKindNone>(sc, in, slot, 0u, false, slot != kNullEntry, max_depth, a);
-        if (a.live) {
-            const uint32_t og = a.orig;
-            lfx[og] = a.L.x;
-            lfy[og] = a.L.y;
-            lfz[og] = a.L.z;
-        }
+        const bool valid = slot != kNullEntry;
+        ShadeA a{};
+        shade_a<FEAT, kKindNone>(sc, in, slot & kSlotMask, 0u, false, valid && pending, valid, max_depth, a);
+        if (a.live) film_put(lf, a.orig, a.L);
     }
 }
 
@@ -954,7 +962,7 @@ __global__ __launch_bounds__(256) void k_shade_light(DevScene sc, PathState in, 
 template <int FEAT, bool COUNT>
 __global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathState buf1, Ctl* ctl,
                                              uint32_t it_abs, uint32_t max_depth, const uint32_t* __restrict__ queue,
-                                             Lists lists, f64_t* lfx, f64_t* lfy, f64_t* lfz, DevStats* stats) {
+                                             Lists lists, f64_t* lf, DevStats* stats) {
     __shared__ int2 lds_stack[kLdsStack * 256];
     __shared__ uint32_t s_job[4][192];  // per wave: slot of the path | ray kind << 30
     __shared__ int2 s_res[4][192];      // per wave: {prim, hit word} found for job j
@@ -1052,8 +1060,8 @@ __global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathS
             asm volatile("" ::: "memory");  // shade_a reads these words back through another pointer type
             int2 hr = make_int2(-1, 0);
             if (has_ex) hr = s_res[wave][jex];
-            ShadeA a;
-            shade_a<FEAT, kKindAny>(sc, in, slot, (uint32_t)hr.y, hr.x >= 0, true, max_depth, a);
+            ShadeA a{};
+            shade_a<FEAT, kKindAny>(sc, in, slot, (uint32_t)hr.y, hr.x >= 0, true, true, max_depth, a);
             ShadeOut r{false, false, false, false};
             if (a.will_shade) {
                 r = shade_b<FEAT>(sc, out, slot, a);
@@ -1063,10 +1071,7 @@ __global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathS
             n_r2 += r.emit_sh ? 1u : 0u;
             n_r3 += r.emit_pr ? 1u : 0u;
             if (!r.keep) {
-                const uint32_t og = a.orig;
-                lfx[og] = a.L.x;
-                lfy[og] = a.L.y;
-                lfz[og] = a.L.z;
+                film_put(lf, a.orig, a.L);
                 alive = false;
             }
         }
@@ -1090,18 +1095,17 @@ __global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathS
 #if defined(RT_KERNELS_CORE) && !defined(RT_F32)  // the film is f64 in both modes: compiled once
 // ------------------------------------------------------------------- resolve
 // util::increment_color order: each pixel's samples are added one by one, in sample order.
-__global__ __launch_bounds__(256) void k_resolve(const double* __restrict__ lfx, const double* __restrict__ lfy,
-                                                 const double* __restrict__ lfz, ChunkDesc ck,
+__global__ __launch_bounds__(256) void k_resolve(const double* __restrict__ lf, ChunkDesc ck,
                                                  const uint32_t* __restrict__ pix_list, double* rgb_sum, uint32_t* n) {
     const uint32_t p_local = blockIdx.x * blockDim.x + threadIdx.x;
     if (p_local >= ck.n_pixels) return;
     const uint32_t pix = pix_list[ck.pixel_base + p_local];
     double r = rgb_sum[(size_t)pix * 3 + 0], g = rgb_sum[(size_t)pix * 3 + 1], b = rgb_sum[(size_t)pix * 3 + 2];
     for (uint32_t s = 0; s < ck.n_samples; s++) {
-        const uint32_t slot = s * ck.n_pixels + p_local;
-        r += lfx[slot];
-        g += lfy[slot];
-        b += lfz[slot];
+        const double* q = lf + (size_t)(s * ck.n_pixels + p_local) * 3;  // kernels.hip: film_put
+        r += q[0];
+        g += q[1];
+        b += q[2];
     }
     rgb_sum[(size_t)pix * 3 + 0] = r;
     rgb_sum[(size_t)pix * 3 + 1] = g;

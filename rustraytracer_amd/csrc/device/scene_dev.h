@@ -114,10 +114,11 @@ struct DevScene {
 // with separate arrays a gathered wave touched 13-27 lines per load instead of 4.
 // Fields are addressed in 8-byte words (a vec3 is three consecutive words); the fast mode keeps its binary32 values in
 // the low half of each word.  Two such pools ping-pong per bounce (kernels.hip).
-//   atom 0  w0-2 o   w3-5 d   w6 rng   w7 {orig, flags}          camera sample / extension ray: ONE atom
-//   atom 1  w8-10 sp   w11-13 beta   w14 {sh_prim, pr_prim}   w15 {hit_prim, hit word}  (w15: k_tail / rt_intersect_batch only)
-//   atom 2  w16-18 L   w19-21 A   w22-23 Q.xy
-//   atom 3  w24 Q.z   w25-27 K   w28-30 pd   w31 spare
+//   line 0, what every bounce reads and rewrites IN FULL (no partly written HBM atom):
+//     w0-2 o   w3-5 d   w6 rng   w7 {orig, flags}   |   w8-10 beta   w11-13 L   w14 {sh_prim, pr_prim}   w15 {hit_prim, hit word}
+//     (w15: k_tail / rt_intersect_batch only; the first atom alone is a camera sample or an extension ray)
+//   line 1, the pending direct-light terms of the previous vertex -- fetched only by paths that carry any:
+//     w16-18 A   w19-21 Q   w22-24 K   w25-27 sp   w28-30 pd   w31 spare
 // o = ray origin (last hit point; spawn_ray adds no offset), d = extension direction, sp = sampled light point (shadow
 // ray target), pd = MIS probe direction, A / Q = pending light-sample / bsdf-sample terms (f * Le * w / pdf), K = beta at
 // the vertex that produced them, orig = film staging slot (sample_local * n_pixels + pixel_local).
@@ -125,21 +126,23 @@ struct PathState {
     char* rec;
 };
 constexpr uint32_t kRecBytes = 256;
-constexpr int kWO = 0, kWD = 3, kWRng = 6, kWMeta = 7, kWSp = 8, kWBeta = 11, kWRes = 14, kWHit = 15, kWL = 16, kWA = 19, kWQ = 22,
-              kWK = 25, kWPd = 28;
+constexpr int kWO = 0, kWD = 3, kWRng = 6, kWMeta = 7, kWBeta = 8, kWL = 11, kWRes = 14, kWHit = 15, kWA = 16, kWQ = 19, kWK = 22,
+              kWSp = 25, kWPd = 28;
 // flags
 constexpr uint32_t kBounceMask = 0xffu;
 constexpr uint32_t kSpecular = 1u << 8;
 constexpr uint32_t kFoldOnly = 1u << 9;
 constexpr uint32_t kHasShadow = 1u << 10;
 constexpr uint32_t kHasProbe = 1u << 11;
-constexpr uint32_t kFresh = 1u << 13;  // a camera sample k_generate has just written: beta = 1, L = 0 are implied, not stored
 constexpr uint32_t kLightShift = 16;
 
-// queue entry = slot | kind << 30; kRayNone fills the unused end of a wave's queue chunk
+// queue entry = slot | kQPending | kind << 30; kRayNone fills the unused end of a wave's queue chunk.  kQPending (extension
+// entries): the path carries pending light terms, i.e. its shading kernel will want line 1 of the record -- the traversal
+// kernel hands the bit on in the list entry (kEntPending), so that the loads of line 1 are issued with those of line 0
 constexpr uint32_t kRayExt = 0u, kRayShadow = 1u, kRayProbe = 2u, kRayNone = 3u;
-constexpr uint32_t kSlotMask = 0x3fffffffu;
+constexpr uint32_t kSlotMask = 0x1fffffffu, kQPending = 1u << 29;
 constexpr uint32_t kNullEntry = 0xffffffffu;  // unused queue / list entry
+constexpr uint32_t kEntPending = 1u << 30;    // in ListEnt::slot
 
 // ---- vertex classes (round 4).  Every primitive belongs to a class = (smallest shading-kernel instance that covers its
 // material, kind of hit record: mesh slot / sphere-rect / generic); class 0 = the extension ray escaped.  A leaf's class

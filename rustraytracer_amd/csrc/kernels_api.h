@@ -14,16 +14,15 @@ using namespace rtc;
 constexpr int kVariants = 9;  // shading.h: kNumFeatVariants
 
 typedef void (*ShadeClsKernel)(DevScene, PathState, PathState, Ctl*, uint32_t, uint32_t, Lists, uint32_t, uint32_t*, uint32_t,
-                               uint32_t, double*, double*, double*, DevStats*);
-typedef void (*ShadeLightKernel)(DevScene, PathState, Ctl*, uint32_t, uint32_t, Lists, double*, double*, double*);
-typedef void (*TailKernel)(DevScene, PathState, PathState, Ctl*, uint32_t, uint32_t, const uint32_t*, Lists, double*, double*,
-                           double*, DevStats*);
+                               uint32_t, double*, DevStats*);
+typedef void (*ShadeLightKernel)(DevScene, PathState, Ctl*, uint32_t, uint32_t, Lists, double*);
+typedef void (*TailKernel)(DevScene, PathState, PathState, Ctl*, uint32_t, uint32_t, const uint32_t*, Lists, double*, DevStats*);
 typedef void (*TraceKernel)(DevScene, PathState, const uint32_t*, Ctl*, uint32_t, DevStats*, TraceTune, MirrorEntry*, uint32_t,
                             const BatchCtl*, unsigned long long, Lists);
 typedef void (*GenKernel)(PathState, rt_camera, ChunkDesc, const uint32_t*, uint32_t*, const Ctl*);
 typedef void (*PlanKernel)(Ctl*, BatchCtl*, uint32_t, uint32_t, unsigned long long, DevStats*);
 typedef void (*IntersectKernel)(DevScene, const rt_ray*, uint64_t, rt_hit*);
-typedef void (*ResolveKernel)(const double*, const double*, const double*, ChunkDesc, const uint32_t*, double*, uint32_t*);
+typedef void (*ResolveKernel)(const double*, ChunkDesc, const uint32_t*, double*, uint32_t*);
 typedef void (*TonemapKernel)(const double*, const uint32_t*, uint64_t, uint8_t*);
 
 struct KernelTable {
