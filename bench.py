@@ -115,34 +115,40 @@ def cpu_baseline(scene, W, H, target_s=9.0):
     return out
 
 
-_ASSET_DIR = None
+_ASSET_DIRS = {}
 
 
-def asset_dir(spec):
+def asset_dir(spec, preset="material_hdr"):
     """Where the row-f4 presets (material_hdr, teapot_hdr) find the reference's data files.  "golden" (default): the
     committed fixtures tests/golden/assets/material (Mesh000/001.obj gzip-compressed, envmap.hdr), unpacked once into
-    a temporary directory -- they travel to the GPU box with the repo; "none": procedural stand-ins for everything; any
-    other value: a directory laid out like the reference's data/material (the build container has
-    /root/reference/data/material)."""
-    global _ASSET_DIR
+    a temporary directory (removed at exit) -- they travel to the GPU box with the repo; "none": procedural stand-ins for
+    everything; any other value: a directory laid out like the reference's data/material (the build container has
+    /root/reference/data/material).
+    teapot_hdr() gets a directory that holds the environment map ONLY: its own two meshes are not in the reference's
+    checkout, and a directory with models/Mesh000.obj + Mesh001.obj in it would make the preset load the material-preview
+    meshes in place of the procedural lid and body (the round-3 "teapot" row measured exactly that)."""
     if spec == "none":
         return None
     if spec != "golden":
         return spec
-    if _ASSET_DIR is None:
+    key = "env_only" if preset == "teapot_hdr" else "full"
+    if key not in _ASSET_DIRS:
+        import atexit
         import gzip
         import shutil
         import tempfile
         src = os.path.join(ROOT, "tests", "golden", "assets", "material")
         out = tempfile.mkdtemp(prefix="rr_assets_")
-        os.makedirs(os.path.join(out, "models"))
+        atexit.register(shutil.rmtree, out, ignore_errors=True)
         os.makedirs(os.path.join(out, "textures"))
-        for name in ("Mesh000.obj", "Mesh001.obj"):
-            with gzip.open(os.path.join(src, "models", name + ".gz"), "rb") as fi, open(os.path.join(out, "models", name), "wb") as fo:
-                shutil.copyfileobj(fi, fo)
+        if key == "full":
+            os.makedirs(os.path.join(out, "models"))
+            for name in ("Mesh000.obj", "Mesh001.obj"):
+                with gzip.open(os.path.join(src, "models", name + ".gz"), "rb") as fi, open(os.path.join(out, "models", name), "wb") as fo:
+                    shutil.copyfileobj(fi, fo)
         shutil.copy(os.path.join(src, "textures", "envmap.hdr"), os.path.join(out, "textures", "envmap.hdr"))
-        _ASSET_DIR = out
-    return _ASSET_DIR
+        _ASSET_DIRS[key] = out
+    return _ASSET_DIRS[key]
 
 
 ASSETS = "golden"
@@ -160,13 +166,16 @@ class Bench:
         self.name, self.rank, self.world, self.coll_dev = name, rank, world, coll_dev
         preset, kw, self.W, self.H, self.spp, self.desc = WORKLOADS[name]
         if preset in ("material_hdr", "teapot_hdr"):
-            kw = dict(kw, mesh_path=asset_dir(ASSETS))
+            kw = dict(kw, mesh_path=asset_dir(ASSETS, preset))
         self.scene = rr.Scene(preset, self.W / self.H, **kw)
         # (the extra rows run on the headline bench's context: one pool of path state per GPU -- 140 GB at the default size)
         self.own_ctx = ctx is None
         self.ctx = rr.Context(local_rank) if ctx is None else ctx
         self.gs = self.ctx.upload(self.scene)
         self.info = self.gs.info()
+        if preset == "teapot_hdr" and ASSETS == "golden":
+            # the procedural body (mesh_faces) + lid (an eighth of it), not whatever meshes the asset directory happens to hold
+            assert self.info["n_triangles"] == kw["mesh_faces"] + kw["mesh_faces"] // 8, (self.info["n_triangles"], kw["mesh_faces"])
         self.d_rgb = torch.zeros((self.H, self.W, 3), dtype=torch.float64, device="cuda")
         self.d_n = torch.zeros((self.H, self.W), dtype=torch.int32, device="cuda")
         self.pif = paths_in_flight

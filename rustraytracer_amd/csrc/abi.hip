@@ -21,6 +21,7 @@
 #include <unistd.h>
 
 #include "bvh_build.h"
+#include "bvh_cache.h"
 #include "bvh_gpu.h"
 #include "env_dist.h"
 #include "device/shading.h"  // geom.h (k_wf_collect re-runs a winner's own test) + the shading-feature masks
@@ -63,6 +64,7 @@ struct Lane {
     uint32_t pool_cls = 0;  // class lists the pool was laid out for
     PathState st[2] = {};
     uint32_t* queue[2] = {nullptr, nullptr};
+    uint32_t* hitw = nullptr;  // the extension rays' hit words, by queue position (k_trace -> k_classify)
     Lists lists{};          // class lists + fold lists (scene_dev.h)
     uint32_t slot_cap = 0;  // records per pool = capacity + room for the unused ends of the waves' chunks
     uint32_t q_cap = 0;     // entries per ray queue
@@ -160,7 +162,7 @@ static void pool_layout(uint32_t cap, uint32_t n_cls, size_t& slots, size_t& qn,
     // of a launch's entries per kernel (kernels.hip: pick_chunk), summed generously
     slots = (size_t)cap + cap / 8 + 65536;
     qn = 3 * slots;
-    bytes = slots * (2 * (size_t)kRecBytes + 2 * sizeof(uint32_t)) + 2 * qn * sizeof(uint32_t) + (size_t)n_cls * slots * sizeof(ListEnt) + 4096;
+    bytes = slots * (2 * (size_t)kRecBytes + 2 * sizeof(uint32_t)) + 3 * qn * sizeof(uint32_t) + (size_t)n_cls * slots * sizeof(ListEnt) + 4096;
 }
 
 static int ensure_lane_capacity(rt_context* c, Lane& ln, uint32_t cap, uint32_t n_cls) {
@@ -193,6 +195,7 @@ static int ensure_lane_capacity(rt_context* c, Lane& ln, uint32_t cap, uint32_t 
     ln.lists.ent = (ListEnt*)p; p += (size_t)n_cls * slots * sizeof(ListEnt);
     ln.queue[0] = (uint32_t*)p; p += qn * sizeof(uint32_t);
     ln.queue[1] = (uint32_t*)p; p += qn * sizeof(uint32_t);
+    ln.hitw = (uint32_t*)p; p += qn * sizeof(uint32_t);
     ln.lists.fold[0] = (uint32_t*)p; p += slots * sizeof(uint32_t);
     ln.lists.fold[1] = (uint32_t*)p; p += slots * sizeof(uint32_t);
     ln.lists.cap = (uint32_t)slots;
@@ -525,125 +528,7 @@ __global__ __launch_bounds__(256) void k_set_leaf_cls(uint32_t* leaf_prim, const
 
 static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cache);
 
-// ---- host BVH shared between the processes of one node (RT_BVH_CACHE=<directory>, e.g. /dev/shm/...)
-// bench.py --gpus N runs one process per GPU and every rank commits the same scene: without this, eight ranks each
-// run the 16-thread SAH build of 1.74 M primitives at the same time on the same host cores.  With the variable set,
-// the ranks take an exclusive flock() on <dir>/rtbvh_<key>.lock in turn: the first one builds and publishes
-// <dir>/rtbvh_<key>.bin (write to a temporary name, then rename), the others read it.  The key hashes everything
-// build_bvh() looks at -- the primitive records incl. their f64 boxes -- and a format tag; a file that fails any
-// check is ignored and rebuilt.  Results cannot depend on it: the tree only culls (geom.h), and the file holds
-// exactly what build_bvh() returned.
-struct BvhCacheHeader {
-    char magic[8];  // "RTBVH\0\0\2"
-    uint64_t key, n_prims, n_nodes;
-    uint32_t depth, node_bytes;
-    uint64_t payload_sum;  // bvh_cache_sum over nodes and order: a torn or damaged file is rebuilt, not uploaded
-};
-static uint64_t bvh_cache_sum(const BvhOut& b) {
-    uint64_t h = 0xcbf29ce484222325ull;
-    auto mix = [&](const void* p, size_t bytes) {
-        const unsigned char* c = static_cast<const unsigned char*>(p);
-        size_t i = 0;
-        for (; i + 8 <= bytes; i += 8) {
-            uint64_t w;
-            std::memcpy(&w, c + i, 8);
-            h = (h ^ w) * 0x100000001b3ull;
-            h ^= h >> 31;
-        }
-        for (; i < bytes; i++) h = (h ^ c[i]) * 0x100000001b3ull;
-    };
-    mix(b.nodes.data(), b.nodes.size() * sizeof(DevNode));
-    mix(b.order.data(), b.order.size() * sizeof(uint32_t));
-    return h;
-}
-static uint64_t bvh_cache_key(const rt_primitive* prims, size_t n) {
-    uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)sizeof(DevNode) ^ ((uint64_t)kLeafTargetPrims << 32);
-    const unsigned char* b = reinterpret_cast<const unsigned char*>(prims);
-    const size_t bytes = n * sizeof(rt_primitive);
-    size_t i = 0;
-    for (; i + 8 <= bytes; i += 8) {  // FNV-1a over 64-bit words (the records are a multiple of 8 bytes)
-        uint64_t w;
-        std::memcpy(&w, b + i, 8);
-        h = (h ^ w) * 0x100000001b3ull;
-        h ^= h >> 29;
-    }
-    for (; i < bytes; i++) h = (h ^ b[i]) * 0x100000001b3ull;
-    return h ^ (uint64_t)n;
-}
-static bool bvh_cache_load(const std::string& path, uint64_t key, size_t np, BvhOut& out) {
-    FILE* f = fopen(path.c_str(), "rb");
-    if (!f) return false;
-    BvhCacheHeader hd;
-    bool ok = fread(&hd, sizeof(hd), 1, f) == 1 && std::memcmp(hd.magic, "RTBVH\0\0\2", 8) == 0 && hd.key == key &&
-              hd.n_prims == np && hd.node_bytes == sizeof(DevNode) && hd.n_nodes > 0 && hd.n_nodes <= 2 * np + 2;
-    if (ok) {
-        out.nodes.resize(hd.n_nodes);
-        out.order.resize(np);
-        out.depth = hd.depth;
-        ok = fread(out.nodes.data(), sizeof(DevNode), hd.n_nodes, f) == hd.n_nodes &&
-             fread(out.order.data(), sizeof(uint32_t), np, f) == np;
-        ok = ok && bvh_cache_sum(out) == hd.payload_sum;
-        // (belt and braces: nothing the traversal would follow may point outside the arrays)
-        for (size_t i = 0; ok && i < np; i++) ok = out.order[i] < np;
-        for (size_t i = 0; ok && i < out.nodes.size(); i++)
-            for (int k = 0; ok && k < 4; k++) {
-                const int32_t c = out.nodes[i].child[k];
-                if (c == kNoChild) continue;
-                if (c >= 0)
-                    ok = (uint64_t)c < hd.n_nodes;
-                else {
-                    const uint32_t code = (uint32_t)(-1 - c) & ~kLeafCodeOther;
-                    ok = (uint64_t)(code >> 3) + (code & 7u) < np;
-                }
-            }
-    }
-    fclose(f);
-    return ok;
-}
-static void bvh_cache_store(const std::string& path, uint64_t key, size_t np, const BvhOut& bvh) {
-    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
-    FILE* f = fopen(tmp.c_str(), "wb");
-    if (!f) return;
-    BvhCacheHeader hd{};
-    std::memcpy(hd.magic, "RTBVH\0\0\2", 8);
-    hd.payload_sum = bvh_cache_sum(bvh);
-    hd.key = key;
-    hd.n_prims = np;
-    hd.n_nodes = bvh.nodes.size();
-    hd.depth = bvh.depth;
-    hd.node_bytes = sizeof(DevNode);
-    const bool ok = fwrite(&hd, sizeof(hd), 1, f) == 1 &&
-                    fwrite(bvh.nodes.data(), sizeof(DevNode), bvh.nodes.size(), f) == bvh.nodes.size() &&
-                    fwrite(bvh.order.data(), sizeof(uint32_t), np, f) == np;
-    if (fclose(f) != 0 || !ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());
-}
-// build_bvh() once per node: returns 1 when the tree came from the cache, 0 when this process built it
-static int build_bvh_shared(const rt_primitive* prims, size_t np, BvhOut& bvh) {
-    const char* dir = getenv("RT_BVH_CACHE");
-    if (!dir || !*dir || np < 4096) {  // small scenes build in milliseconds
-        build_bvh(prims, np, bvh);
-        return 0;
-    }
-    const uint64_t key = bvh_cache_key(prims, np);
-    char name[64];
-    snprintf(name, sizeof(name), "/rtbvh_%016llx", (unsigned long long)key);
-    const std::string base = std::string(dir) + name;
-    const int lock = open((base + ".lock").c_str(), O_CREAT | O_RDWR, 0600);
-    if (lock >= 0) (void)flock(lock, LOCK_EX);  // (no lock, e.g. a read-only directory: everybody builds, as before)
-    int from_cache = 0;
-    if (bvh_cache_load(base + ".bin", key, np, bvh)) {
-        from_cache = 1;
-    } else {
-        bvh = BvhOut{};
-        build_bvh(prims, np, bvh);
-        if (lock >= 0) bvh_cache_store(base + ".bin", key, np, bvh);
-    }
-    if (lock >= 0) {
-        (void)flock(lock, LOCK_UN);
-        close(lock);
-    }
-    return from_cache;
-}
+// (host BVH shared between the processes of one node, RT_BVH_CACHE: bvh_cache.cpp)
 
 // The builder emits nodes depth-first.  Move the top of the tree -- the first `n_top` nodes met breadth-first from the
 // root, which every ray walks -- to the front, in that order: they then share a few cache lines, and a kernel can hold
@@ -1198,7 +1083,10 @@ static int run_lane(RenderJob& job, int lane_id) {
         const uint32_t seq = seq0 + (uint32_t)it;
         hipLaunchKernelGGL(trace_kernel(job.count_trav, job.s->dev.simple_others != 0, job.f32_trace), dim3(tblocks), dim3(256), 0, stream,
                            job.s->dev, ln.st[it & 1], ln.queue[it & 1], ln.ctl, (uint32_t)it, c->stats, c->tune,
-                           no_mirror ? nullptr : ln.mirror_d, seq, c->batch, job.batch_total, ln.lists);
+                           no_mirror ? nullptr : ln.mirror_d, seq, c->batch, job.batch_total, ln.hitw);
+        // the traced paths to the lists of their vertex classes (a streaming pass over the queue)
+        hipLaunchKernelGGL(rtk::kernel_table().classify, dim3(std::min((3u * bound_active + 255u) / 256u + 1u, (uint32_t)c->num_cus * 8u)), dim3(256), 0,
+                           stream, ln.queue[it & 1], ln.hitw, ln.ctl, (uint32_t)it, ln.lists);
         if (!no_ev) {
             LANE_TRY(hipEventRecord(b, stream));
             ln.trace_ev.emplace_back(a, b);
@@ -1819,9 +1707,9 @@ int rt_intersect_batch_ex(rt_context* c, rt_scene* s, const rt_ray* rays, uint64
             const unsigned tblocks = std::max(1u, std::min(blocks, (unsigned)(c->num_cus * std::max(1, occ))));
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(k_wf_setup, dim3(blocks), dim3(256), 0, c->stream, d_rays, (uint32_t)n, ln.st[0], ln.queue[0], ln.ctl, f32 ? 1 : 0);
-                // (no class lists: the extension rays' results go into their records, kernels.hip: k_trace)
+                // (no hit-word array: the extension rays' results go into their records, kernels.hip: k_trace)
                 hipLaunchKernelGGL(tk, dim3(tblocks), dim3(256), 0, c->stream, s->dev, ln.st[0], ln.queue[0], ln.ctl, 0u, c->stats,
-                                   c->tune, (MirrorEntry*)nullptr, 0u, c->batch, 0ull, Lists{});
+                                   c->tune, (MirrorEntry*)nullptr, 0u, c->batch, 0ull, (uint32_t*)nullptr);
                 hipLaunchKernelGGL(k_wf_collect, dim3(blocks), dim3(256), 0, c->stream, s->dev, d_rays, (uint32_t)n, ln.st[0], d_hits);
                 e = hipGetLastError();
             }

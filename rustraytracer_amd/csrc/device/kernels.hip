@@ -103,6 +103,42 @@ RTD void st_beta_l(rt_w* r, D3 beta, D3 l) {
     q.x = 0ull; q.y = 0ull;
     *reinterpret_cast<rt_w2*>(r + 14) = q;
 }
+// ---- whole-line stores of line 0.  A lane that writes its own record sends eight 16-B stores to a line of its own: 64
+// partly written lines per instruction (k_generate ran at 2.8 TB/s that way).  Instead every lane of a wave deposits its
+// line in LDS (pitch 9 pairs: conflict-free) and the wave writes the lines together, eight lanes per 128-B line.
+constexpr int kStagePitch = 9;                      // pairs per staged line (8 + 1 pad)
+constexpr int kStageWave = 64 * kStagePitch + 16;   // pairs per wave: 64 lines + their slots (64 x 4 B)
+RTD void stage_line(rt_w2* s, uint32_t rank, uint32_t slot, D3 o, D3 d, uint64_t rng, uint32_t orig, uint32_t flags, D3 beta, D3 l) {
+    rt_w2* q = s + rank * kStagePitch;
+    rt_w2 v;
+    v.x = r2w(o.x); v.y = r2w(o.y); q[0] = v;
+    v.x = r2w(o.z); v.y = r2w(d.x); q[1] = v;
+    v.x = r2w(d.y); v.y = r2w(d.z); q[2] = v;
+    v.x = rng; v.y = (rt_w)orig | ((rt_w)flags << 32); q[3] = v;
+    v.x = r2w(beta.x); v.y = r2w(beta.y); q[4] = v;
+    v.x = r2w(beta.z); v.y = r2w(l.x); q[5] = v;
+    v.x = r2w(l.y); v.y = r2w(l.z); q[6] = v;
+    v.x = 0ull; v.y = 0ull; q[7] = v;
+    reinterpret_cast<uint32_t*>(s + 64 * kStagePitch)[rank] = slot;
+}
+// lines 0 .. cnt-1 of the wave's staging area go to their records (a slot of kNullEntry: nothing staged at that rank)
+RTD void stage_flush(rt_w2* s, const PathState& st, uint32_t cnt) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t lane = threadIdx.x & 63u, part = lane & 7u;
+    const uint32_t* slots = reinterpret_cast<const uint32_t*>(s + 64 * kStagePitch);
+    for (uint32_t j0 = 0; j0 < cnt; j0 += 8u) {
+        const uint32_t j = j0 + (lane >> 3);
+        if (j < cnt) {
+            const uint32_t slot = slots[j];
+            if (slot != kNullEntry) reinterpret_cast<rt_w2*>(st.rec + (size_t)slot * kRecBytes)[part] = s[j * kStagePitch + part];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // (the area is reused by the wave's next group)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 // a record's pairs in registers (the fields a kernel wants are fetched up front, independent of each other)
 struct RecRegs {
     rt_w2 p[16];
@@ -202,43 +238,48 @@ __global__ void k_plan(Ctl* ctl, BatchCtl* batch, uint32_t it, uint32_t pool, un
 __global__ __launch_bounds__(256) void k_generate(PathState st, rt_camera cam, ChunkDesc ck,
                                                   const uint32_t* __restrict__ pix_list, uint32_t* queue,
                                                   const Ctl* ctl) {
+    __shared__ rt_w2 s_stage[4][kStageWave];
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= ctl->gen_count) return;
+    const uint32_t n_gen = ctl->gen_count;
+    if (blockIdx.x * blockDim.x >= n_gen) return;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t wave_first = idx - lane;  // wave-uniform
+    const bool valid = idx < n_gen;
     const uint32_t g = ctl->gen_first + idx;  // path index inside the batch = film staging slot
     const uint32_t slot = ctl->gen_slot + idx;
-    const uint32_t s_local = g / ck.n_pixels, p_local = g - s_local * ck.n_pixels;
-    const uint32_t pix = pix_list[ck.pixel_base + p_local];
-    const uint32_t px = pix % ck.width, py = pix / ck.width;
-    uint64_t rng = rng_init(ck.seed, (uint64_t)pix, (uint64_t)(ck.sample_base + s_local));
-    const double ox = rng_next(rng), oy = rng_next(rng);
-    (void)rng_next(rng);  // time
-    (void)rng_next(rng);  // lens.x
-    (void)rng_next(rng);  // lens.y
-    const double fx = (double)px + ox, fy = (double)py + oy;
-    const double u = fx / (double)ck.width, v = fy / (double)ck.height;
-    double dx, dy;
-    for (;;) {  // rand_in_disk
-        dx = rng_next(rng);
-        dy = rng_next(rng);
-        if (dx * dx + dy * dy < 1.0) break;
+    if (valid) {
+        const uint32_t s_local = g / ck.n_pixels, p_local = g - s_local * ck.n_pixels;
+        const uint32_t pix = pix_list[ck.pixel_base + p_local];
+        const uint32_t px = pix % ck.width, py = pix / ck.width;
+        uint64_t rng = rng_init(ck.seed, (uint64_t)pix, (uint64_t)(ck.sample_base + s_local));
+        const double ox = rng_next(rng), oy = rng_next(rng);
+        (void)rng_next(rng);  // time
+        (void)rng_next(rng);  // lens.x
+        (void)rng_next(rng);  // lens.y
+        const double fx = (double)px + ox, fy = (double)py + oy;
+        const double u = fx / (double)ck.width, v = fy / (double)ck.height;
+        double dx, dy;
+        for (;;) {  // rand_in_disk
+            dx = rng_next(rng);
+            dy = rng_next(rng);
+            if (dx * dx + dy * dy < 1.0) break;
+        }
+        const D3 in_disk = d3(dx, dy, 0.0) * cam.lens_radius;
+        const D3 cu = d3(cam.u[0], cam.u[1], cam.u[2]), cv = d3(cam.v[0], cam.v[1], cam.v[2]);
+        const D3 offset = cu * in_disk.x + cv * in_disk.y;
+        const D3 origin = d3(cam.origin[0], cam.origin[1], cam.origin[2]);
+        const D3 ulc = d3(cam.upper_left_corner[0], cam.upper_left_corner[1], cam.upper_left_corner[2]);
+        const D3 ho = d3(cam.horizontal_offset[0], cam.horizontal_offset[1], cam.horizontal_offset[2]);
+        const D3 vo = d3(cam.vertical_offset[0], cam.vertical_offset[1], cam.vertical_offset[2]);
+        const D3 to = ulc + ho * u - vo * v;
+        const D3 dir = to - origin;
+        (void)rng_next(rng);  // rand_range(t0, t1)
+        // line 0 of the record in full: o, d, rng, {orig, flags}, beta = 1, L = 0 (whole-line stores, see stage_line)
+        stage_line(s_stage[wave], lane, slot, origin + offset, dir - offset, rng, g, 0u, white(), black());
+        queue[ctl->gen_q + idx] = slot | (kRayExt << 30);
     }
-    const D3 in_disk = d3(dx, dy, 0.0) * cam.lens_radius;
-    const D3 cu = d3(cam.u[0], cam.u[1], cam.u[2]), cv = d3(cam.v[0], cam.v[1], cam.v[2]);
-    const D3 offset = cu * in_disk.x + cv * in_disk.y;
-    const D3 origin = d3(cam.origin[0], cam.origin[1], cam.origin[2]);
-    const D3 ulc = d3(cam.upper_left_corner[0], cam.upper_left_corner[1], cam.upper_left_corner[2]);
-    const D3 ho = d3(cam.horizontal_offset[0], cam.horizontal_offset[1], cam.horizontal_offset[2]);
-    const D3 vo = d3(cam.vertical_offset[0], cam.vertical_offset[1], cam.vertical_offset[2]);
-    const D3 to = ulc + ho * u - vo * v;
-    const D3 dir = to - origin;
-    (void)rng_next(rng);  // rand_range(t0, t1)
-    // line 0 of the record in full (eight 16-B stores, no partly written atom): o, d, rng, {orig, flags}, beta = 1, L = 0
-    rt_w* r = rec_words(st, slot);
-    st3w<kWO>(r, origin + offset);
-    st3w<kWD>(r, dir - offset);
-    st_meta(r, rng, g, 0u);
-    st_beta_l(r, white(), black());
-    queue[ctl->gen_q + idx] = slot | (kRayExt << 30);
+    const uint32_t left = wave_first < n_gen ? n_gen - wave_first : 0u;
+    stage_flush(s_stage[wave], st, left < 64u ? left : 64u);
 }
 #endif  // RT_KERNELS_CORE
 
@@ -254,16 +295,17 @@ __global__ __launch_bounds__(256) void k_generate(PathState st, rt_camera cam, C
 //   * Every wave step is EITHER a node step OR a single-primitive step, whichever more lanes are
 //     waiting for (majority scheduling): the wave never runs the primitive code for the sake of a few
 //     lanes while the rest are walking the tree, and vice versa.
-//   * Results: a shadow / probe ray writes the primitive it found into its path's record; an extension ray is
-//     appended as {slot, hit word} to the list of the hit's vertex class (lists.ent; per-wave chunks per class, cursors in
-//     LDS).  lists.ent == null (k_tail does not use this kernel; rt_intersect_batch_ex does): the extension result goes
-//     into the record as well.
+//   * Results: a shadow / probe ray writes the primitive it found into its path's record; an extension ray writes its
+//     hit word (scene_dev.h) at its QUEUE position (hitw[]: neighbouring lanes, neighbouring words), from where k_classify
+//     deals the paths to the lists of their vertex classes.  (Appending to the class lists here -- a cursor per class, a
+//     ballot per class and refill round -- was measured: +10 % on every launch of this kernel, camera rays included.)
+//     hitw == null (rt_intersect_batch_ex): the extension result goes into the record as well.
 // Every wave leaves the loop once the queue is exhausted and its own lanes are done.
 template <bool COUNT, bool SIMPLE>
 __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, PathState st, const uint32_t* __restrict__ queue,
                                                Ctl* ctl, uint32_t it_abs, DevStats* stats, TraceTune tune,
                                                MirrorEntry* mirror, uint32_t seq, const BatchCtl* batch,
-                                               unsigned long long batch_total, Lists lists) {
+                                               unsigned long long batch_total, uint32_t* hitw) {
     const uint32_t it = it_abs % kRing;
     const uint32_t n = ctl->n_rays[it];
     const unsigned long long t_start = COUNT ? wall_clock64() : 0ull;
@@ -278,22 +320,17 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
     // (the wave's number made wave-uniform for the compiler too: what is indexed / looped with it then lives in SGPRs)
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t n_waves = gridDim.x * 4u;
-    uint32_t* const cls_counters = &ctl->cls_count[it_abs & 3u][0][0];
-    const uint32_t list_chunk = pick_chunk(n, n_waves);
     if (sc.n_nodes == 0) {  // a scene without primitives (an environment only): every query misses
         for (uint32_t i0 = blockIdx.x * 256u + wave * 64u; i0 < n; i0 += gridDim.x * 256u) {
             const uint32_t i = i0 + lane;
             const uint32_t e = i < n ? queue[i] : kNullEntry;
             const uint32_t slot = e & kSlotMask, kind = e >> 30;
             const bool ext = kind == kRayExt;
-            if (lists.ent) {
-                const unsigned long long m = __ballot(ext);
-                if (m) {
-                    const uint32_t at = wave_atomic_add(cls_counters, (uint32_t)__popcll(m)) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    if (ext && at < lists.cap) lists.ent[at] = ListEnt{slot | ((e & kQPending) ? kEntPending : 0u), 0u};
-                }
-            } else if (ext) {
-                reinterpret_cast<int32_t*>(rec_words(st, slot) + kWHit)[0] = -1;
+            if (ext) {
+                if (hitw)
+                    hitw[i] = 0u;
+                else
+                    reinterpret_cast<int32_t*>(rec_words(st, slot) + kWHit)[0] = -1;
             }
             if (kind == kRayShadow) reinterpret_cast<int32_t*>(rec_words(st, slot) + kWRes)[0] = -1;
             if (kind == kRayProbe) reinterpret_cast<int32_t*>(rec_words(st, slot) + kWRes)[1] = -1;
@@ -305,12 +342,6 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
     if (blockIdx.x * 256u >= n) return;
     TravCount tc{0, 0, 0};
     __shared__ int2 lds_stack[kLdsStack * 256];
-    // per wave and class: the wave's chunk of that class list ({next free entry, end})
-    __shared__ volatile uint32_t s_cls[4][kMaxCls][2];
-    if (lane < (uint32_t)kMaxCls) {
-        s_cls[wave][lane][0] = 0u;
-        s_cls[wave][lane][1] = 0u;
-    }
     RT_TRAV_STACK(ts, lds_stack)
 #if RT_LDS_NODES > 0
     // BASELINE north_star: "BVH-node tiles staged in LDS" -- the first RT_LDS_NODES nodes, the top of the tree, which
@@ -336,7 +367,7 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
     uint32_t diag_rounds[4] = {0, 0, 0, 0};  // wave-uniform diagnostics (instrumented build only)
     uint32_t diag_max_steps = 0, diag_over[2] = {0, 0};  // per lane: longest traversal, rays over 64 / 256 steps
     bool exhausted = false;  // wave-uniform: the queue and this wave's reservation have no more entries
-    uint32_t slot_kind = 0;
+    uint32_t slot_kind = 0, q_idx = 0;  // the lane's queue entry and its position
     uint32_t res_next = 0, res_end = 0;  // wave-uniform: [res_next, res_end) is reserved for this wave
     uint32_t res_base = 0, q_lo = 0, q_hi = 0;  // start of the reservation; its queue entries, two per lane
     // One atomic on the queue head hands a wave `reserve` entries.  128 is the measured optimum: 64 costs 30 % of the
@@ -361,33 +392,16 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
         if (n_idle >= tune.refill_lanes || exhausted) {
             const uint32_t slot = slot_kind & kSlotMask, kind = slot_kind >> 30;
             const bool wb_ext = wb && kind == kRayExt;
-            if (lists.ent) {
-                // extension rays: {slot, hit word} goes to the list of the hit's class, class by class (a handful per round)
+            if (wb_ext) {
                 const uint32_t hw = tv.best_prim < 0 ? 0u : hit_word(tv.best_prim, tv.best_slot);
-                const uint32_t cls = hw >> kClsShift & (uint32_t)(kMaxCls - 1);
-                unsigned long long pend = __ballot(wb_ext);
-                while (pend) {
-                    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cls, __ffsll((long long)pend) - 1);
-                    const bool mine = wb_ext && cls == c;
-                    const unsigned long long m = __ballot(mine);
-                    pend &= ~m;
-                    Cursor cu;
-                    cu.cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cls[wave][c][0]);
-                    cu.end = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cls[wave][c][1]);
-                    const uint32_t at = cursor_take(cu, cls_counters + c * 32u, list_chunk, (uint32_t)__popcll(m),
-                                                    (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
-                    if (lane == 0) {
-                        s_cls[wave][c][0] = cu.cur;
-                        s_cls[wave][c][1] = cu.end;
-                    }
-                    if (mine && at < lists.cap)
-                        lists.ent[(size_t)c * lists.cap + at] = ListEnt{slot | ((slot_kind & kQPending) ? kEntPending : 0u), hw};
+                if (hitw) {
+                    hitw[q_idx] = hw;
+                } else {
+                    int2 h;
+                    h.x = tv.best_prim;
+                    h.y = (int)hw;
+                    *reinterpret_cast<int2*>(rec_words(st, slot) + kWHit) = h;
                 }
-            } else if (wb_ext) {
-                int2 h;
-                h.x = tv.best_prim;
-                h.y = (int)(tv.best_prim < 0 ? 0u : hit_word(tv.best_prim, tv.best_slot));
-                *reinterpret_cast<int2*>(rec_words(st, slot) + kWHit) = h;
             }
             if (wb && kind == kRayShadow) reinterpret_cast<int32_t*>(rec_words(st, slot) + kWRes)[0] = tv.best_prim;
             if (wb && kind == kRayProbe) reinterpret_cast<int32_t*>(rec_words(st, slot) + kWRes)[1] = tv.best_prim;
@@ -464,6 +478,7 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
                     }
                     trav_init(tv, sc, o, d, tmin, kInf);
                     slot_kind = e;
+                    q_idx = idx;
                     has_ray = true;
                     if (COUNT) ray_steps0 = tc.nodes + tc.tris + tc.others;
                 }
@@ -501,14 +516,6 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
             }
             wb = true;
             has_ray = false;
-        }
-    }
-    // the unused end of this wave's last chunk of every class list: null entries
-    if (lists.ent && list_chunk) {
-        for (uint32_t c = 0; c < lists.n_cls; c++) {
-            const uint32_t cur = s_cls[wave][c][0], end = s_cls[wave][c][1];
-            for (uint32_t i = cur + lane; i < end; i += 64u)
-                if (i < lists.cap) lists.ent[(size_t)c * lists.cap + i] = ListEnt{kNullEntry, 0u};
         }
     }
     if (COUNT) {
@@ -556,6 +563,65 @@ __global__ __launch_bounds__(256) void k_intersect_batch(DevScene sc, const rt_r
     hits[i] = h;
 }
 #endif  // RT_KERNELS_CORE
+
+// ------------------------------------------------------------------ classify
+// Deals the paths whose extension ray k_trace has just traced to the lists of their vertex classes (scene_dev.h): a
+// streaming pass over the queue and the hit words, 8 + 8 bytes per path.  A wave takes a contiguous span of the queue, so
+// a list chunk holds neighbouring paths in queue order; per class a cursor (SGPRs, the class loop is unrolled) hands out
+// list entries from chunks of the class counter.
+template <int DUMMY>
+__global__ __launch_bounds__(256) void k_classify(const uint32_t* __restrict__ queue, const uint32_t* __restrict__ hitw, Ctl* ctl,
+                                                  uint32_t it_abs, Lists lists) {
+    const uint32_t n = ctl->n_rays[it_abs % kRing];
+    const uint32_t n_groups = (n + 63u) / 64u;
+    const uint32_t lane = threadIdx.x & 63u, n_waves = gridDim.x * 4u;
+    const uint32_t wave_g = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t per_wave = (n_groups + n_waves - 1u) / n_waves;
+    const uint32_t g_first = wave_g * per_wave, g_end = g_first + per_wave < n_groups ? g_first + per_wave : n_groups;
+    if (g_first >= g_end) return;
+    const uint32_t chunk = pick_chunk(n, n_waves < n_groups ? n_waves : n_groups);
+    uint32_t* const counters = &ctl->cls_count[it_abs & 3u][0][0];
+    Cursor ccur[kMaxCls];
+#pragma unroll
+    for (int c = 0; c < kMaxCls; c++) ccur[c] = Cursor{0u, 0u};
+    const unsigned long long below = (1ull << lane) - 1ull;
+    // four groups per round: their eight loads are in flight together (one group at a time, the pass ran at 0.7 TB/s --
+    // 114 ms of a C4 frame -- on nothing but its own load latency)
+    for (uint32_t g0 = g_first; g0 < g_end; g0 += 4u) {
+        uint32_t e4[4], hw4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = (g0 + u) * 64u + lane;
+            const bool in = g0 + u < g_end && i < n;
+            e4[u] = in ? queue[i] : kNullEntry;
+            hw4[u] = in ? hitw[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t e = e4[u], hw = hw4[u];
+            const bool ext = (e >> 30) == kRayExt;
+            if (__ballot(ext) == 0ull) continue;
+            const uint32_t cls = ext ? (hw >> kClsShift & (uint32_t)(kMaxCls - 1)) : (uint32_t)kMaxCls;
+            const uint32_t slot_word = (e & kSlotMask) | ((e & kQPending) ? kEntPending : 0u);
+#pragma unroll
+            for (int c = 0; c < kMaxCls; c++) {
+                if ((uint32_t)c >= lists.n_cls) break;
+                const bool mine = cls == (uint32_t)c;
+                const unsigned long long m = __ballot(mine);
+                if (m) {
+                    const uint32_t at = cursor_take(ccur[c], counters + c * 32, chunk, (uint32_t)__popcll(m), (uint32_t)__popcll(m & below));
+                    if (mine && at < lists.cap) lists.ent[(size_t)c * lists.cap + at] = ListEnt{slot_word, hw};
+                }
+            }
+        }
+    }
+    if (chunk) {
+#pragma unroll
+        for (int c = 0; c < kMaxCls; c++)
+            for (uint32_t i = ccur[c].cur + lane; i < ccur[c].end; i += 64u)
+                if (i < lists.cap) lists.ent[(size_t)c * lists.cap + i] = ListEnt{kNullEntry, 0u};
+    }
+}
 
 // --------------------------------------------------------------------- shade
 // The per-vertex work in two halves:
@@ -695,9 +761,10 @@ struct ShadeOut {
     bool emit_ext, emit_sh, emit_pr, keep;
 };
 
-// Precondition: a.will_shade.  `os` = slot of `out` reserved for this vertex.
+// Precondition: a.will_shade.  `os` = slot of `out` reserved for this vertex.  `stage` (class kernels): the wave's staging
+// area, where line 0 of the survivor's record is deposited as line `rank` for the caller's stage_flush; null: stored here.
 template <int FEAT>
-RTD ShadeOut shade_b(const DevScene& sc, const PathState& out, uint32_t os, ShadeA& a) {
+RTD ShadeOut shade_b(const DevScene& sc, const PathState& out, uint32_t os, ShadeA& a, rt_w2* stage = nullptr, uint32_t rank = 0u) {
     const HitRec& rec = a.rec;
     D3 beta = a.beta;
     uint32_t bounces = a.bounces;
@@ -808,13 +875,18 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& out, uint32_t os, Shad
     r.emit_sh = has_sh;
     r.emit_pr = has_pr;
     r.keep = cont || has_sh || has_pr;
-    if (r.keep) {
-        // line 0 of the record in full (a fold-only path's d / beta are never read)
-        st3w<kWO>(ow, rec.p);  // spawn_ray: origin = hit point (Q4)
+    const uint32_t flags = (bounces & kBounceMask) | (spec ? kSpecular : 0u) | (cont ? 0u : kFoldOnly) | (has_sh ? kHasShadow : 0u) |
+                           (has_pr ? kHasProbe : 0u) | (light_num << kLightShift);
+    // line 0 of the record in full (a fold-only path's d / beta are never read); origin = hit point (spawn_ray, Q4)
+    if (stage) {
+        if (r.keep)
+            stage_line(stage, rank, os, rec.p, wi, rng, a.orig, flags, beta, a.L);
+        else
+            reinterpret_cast<uint32_t*>(stage + 64 * kStagePitch)[rank] = kNullEntry;
+    } else if (r.keep) {
+        st3w<kWO>(ow, rec.p);
         st3w<kWD>(ow, wi);
-        st_meta(ow, rng, a.orig,
-                (bounces & kBounceMask) | (spec ? kSpecular : 0u) | (cont ? 0u : kFoldOnly) | (has_sh ? kHasShadow : 0u) |
-                    (has_pr ? kHasProbe : 0u) | (light_num << kLightShift));
+        st_meta(ow, rng, a.orig, flags);
         st_beta_l(ow, beta, a.L);
     }
     return r;
@@ -856,17 +928,22 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade_cls(DevScen
     // (wave-uniform for the compiler too: the loop below and its cursors then live in SGPRs -- with a per-lane loop counter
     // every cursor is a VGPR and the kernel spills 76-139 registers instead of 8-16)
     const uint32_t wave_g = blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (wave_g >= n_groups) return;
+    // a contiguous span of the list per wave: its queue chunks then hold neighbouring paths in list (= queue) order
+    const uint32_t per_wave = (n_groups + n_waves - 1u) / n_waves;
+    const uint32_t g_first = wave_g * per_wave, g_end = g_first + per_wave < n_groups ? g_first + per_wave : n_groups;
+    if (g_first >= g_end) return;
     const uint32_t chunk = pick_chunk(n, n_waves < n_groups ? n_waves : n_groups);
     const ListEnt* ent = lists.ent + (size_t)cls * lists.cap;
     uint32_t* fold_out = lists.fold[(it_abs + 1u) & 1u];
     uint32_t* const c_slots = &ctl->n_active[itn];
     uint32_t* const c_rays = &ctl->n_rays[itn];
     uint32_t* const c_fold = &ctl->fold_count[(it_abs + 1u) & 3u][0];
+    __shared__ rt_w2 s_stage[4][kStageWave];  // whole-line stores of the survivors' records (stage_line)
+    rt_w2* const stage = s_stage[threadIdx.x >> 6];
     Cursor cs{0u, 0u}, cq0{0u, 0u}, cq1{0u, 0u}, cq2{0u, 0u}, cf{0u, 0u};
     uint32_t n_r1 = 0, n_r2 = 0, n_r3 = 0, n_v = 0;  // wave-uniform
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (uint32_t g = wave_g; g < n_groups; g += n_waves) {
+    for (uint32_t g = g_first; g < g_end; g++) {
         const uint32_t i = g * 64u + lane;
         ListEnt e{kNullEntry, 0u};
         if (i < n) e = ent[i];
@@ -875,12 +952,19 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade_cls(DevScen
         shade_a<FEAT, KIND>(sc, in, e.slot & kSlotMask, e.hit, true, valid && (e.slot & kEntPending), valid, max_depth, a);
         const unsigned long long m = __ballot(a.will_shade);
         uint32_t os = 0;
+        const uint32_t rank = (uint32_t)__popcll(m & below);
         if (m) {
-            os = cursor_take(cs, c_slots, chunk, (uint32_t)__popcll(m), (uint32_t)__popcll(m & below));
+            os = cursor_take(cs, c_slots, chunk, (uint32_t)__popcll(m), rank);
             n_v += (uint32_t)__popcll(m);
         }
         ShadeOut r{false, false, false, false};
-        if (a.will_shade && os < slot_cap) r = shade_b<FEAT>(sc, out, os, a);
+        if (a.will_shade) {
+            if (os < slot_cap)
+                r = shade_b<FEAT>(sc, out, os, a, stage, rank);
+            else
+                reinterpret_cast<uint32_t*>(stage + 64 * kStagePitch)[rank] = kNullEntry;
+        }
+        if (m) stage_flush(stage, out, (uint32_t)__popcll(m));
         if (a.live && !r.keep) film_put(lf, a.orig, a.L);  // retired: its radiance goes to the film staging slot of (pixel, sample)
         // ---- rays of the next bounce, and the paths that only have light terms to fold
         const unsigned long long me = __ballot(r.emit_ext), ms = __ballot(r.emit_sh), mp = __ballot(r.emit_pr);

@@ -146,10 +146,10 @@ constexpr uint32_t kEntPending = 1u << 30;    // in ListEnt::slot
 
 // ---- vertex classes (round 4).  Every primitive belongs to a class = (smallest shading-kernel instance that covers its
 // material, kind of hit record: mesh slot / sphere-rect / generic); class 0 = the extension ray escaped.  A leaf's class
-// rides in bits 27-30 of its leaf_prim word (and so in the traversal's best_slot), the traversal kernel appends every
+// rides in bits 27-29 of its leaf_prim word (and so in the traversal's best_slot), the traversal kernel appends every
 // finished extension ray to the list of its class, and one shading kernel per class runs on waves that are class-pure
 // over the whole launch.
-constexpr int kMaxCls = 16;
+constexpr int kMaxCls = 8;  // (the traversal kernel keeps a list cursor per class in SGPRs)
 constexpr uint32_t kClsShift = 27;
 constexpr uint32_t kIdxMask = (1u << kClsShift) - 1u;  // leaf slot / primitive index part of a leaf_prim or hit word
 // hit word of a list entry: class bits, kLeafOther, and the LEAF SLOT of a mesh hit or the PRIMITIVE INDEX of a sphere /

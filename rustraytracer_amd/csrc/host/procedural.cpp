@@ -7,6 +7,7 @@
 // `load_obj(path, true)`: first model, fan triangulation, single index, f32 data).
 #include <algorithm>
 #include <array>
+#include <cerrno>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -204,7 +205,7 @@ bool parse_obj(const std::string& path, const Mat4& trans, Mesh& out, std::strin
     std::vector<uint32_t> oind;
     bool model_open = false, model_closed = false;
     std::string line;
-    auto fix = [](int i, size_t n) { return i > 0 ? i - 1 : (int)n + i; };
+    auto fix = [](int i, size_t n) { return i > 0 ? i - 1 : (int)((long long)n + i < -1 ? -1 : (long long)n + i); };
     while (std::getline(in, line)) {
         if (!line.empty() && line.back() == '\r') line.pop_back();
         std::istringstream ss(line);
@@ -230,20 +231,37 @@ bool parse_obj(const std::string& path, const Mat4& trans, Mesh& out, std::strin
             std::vector<uint32_t> poly;
             std::string tok;
             while (ss >> tok) {
+                // v, v/vt, v//vn or v/vt/vn; every index a decimal integer that fits an int (sscanf("%d") wraps a value
+                // that does not -- "4294967297" read as 1 -- where tobj fails the parse, so the fields are read with strtoll)
                 Idx id{0, -1, -1};
-                int a = 0, b = 0, c = 0;
-                if (std::sscanf(tok.c_str(), "%d/%d/%d", &a, &b, &c) == 3) {
-                    id = {fix(a, pos.size() / 3), fix(b, tex.size() / 2), fix(c, nor.size() / 3)};
-                } else if (std::sscanf(tok.c_str(), "%d//%d", &a, &c) == 2) {
-                    id = {fix(a, pos.size() / 3), -1, fix(c, nor.size() / 3)};
-                } else if (std::sscanf(tok.c_str(), "%d/%d", &a, &b) == 2) {
-                    id = {fix(a, pos.size() / 3), fix(b, tex.size() / 2), -1};
-                } else if (std::sscanf(tok.c_str(), "%d", &a) == 1) {
-                    id = {fix(a, pos.size() / 3), -1, -1};
-                } else {
+                long long f3[3] = {0, 0, 0};
+                bool have[3] = {false, false, false};
+                int nf = 0;
+                bool bad = false;
+                const char* s = tok.c_str();
+                for (;;) {
+                    if (nf >= 3) { bad = true; break; }
+                    if (*s != '/' && *s != '\0') {
+                        char* end = nullptr;
+                        errno = 0;
+                        const long long v = std::strtoll(s, &end, 10);
+                        if (end == s || errno == ERANGE || v > 2147483647ll || v < -2147483647ll - 1) { bad = true; break; }
+                        f3[nf] = v;
+                        have[nf] = true;
+                        s = end;
+                    }
+                    nf++;
+                    if (*s == '/') { s++; continue; }
+                    if (*s != '\0') bad = true;
+                    break;
+                }
+                if (bad || !have[0] || (nf == 2 && !have[1]) || (nf == 3 && !have[2])) {
                     err = "Failed to parse obj " + path;
                     return false;
                 }
+                id.v = fix((int)f3[0], pos.size() / 3);
+                if (have[1]) id.vt = fix((int)f3[1], tex.size() / 2);
+                if (have[2]) id.vn = fix((int)f3[2], nor.size() / 3);
                 if (id.v < 0 || (size_t)id.v >= pos.size() / 3) {
                     err = "Failed to parse obj " + path;
                     return false;

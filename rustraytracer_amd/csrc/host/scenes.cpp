@@ -275,10 +275,17 @@ static bool material_hdr(const PresetParams& p, FlatScene& out, std::string& err
     Camera camera = Camera::create(from, to, up, p.aspect_ratio, 20., 0.0, 10.);
     const std::string root = (p.mesh_path && p.mesh_path[0]) ? std::string(p.mesh_path) : std::string();
     {
+        // (a MISSING envmap.hdr is replaced by the procedural environment; one that is there but does not decode is an
+        // error -- the reference panics on it, material.rs:632-640 -- not a silent stand-in)
         rt_texture env;
         std::string e2;
-        if (root.empty() || !Texture::new_hdr(o, root + "/textures/envmap.hdr", env, e2))
+        if (root.empty() || !Texture::new_hdr(o, root + "/textures/envmap.hdr", env, e2)) {
+            if (!root.empty() && e2.rfind("Unable to open file", 0) != 0) {
+                err = e2;
+                return false;
+            }
             env = Texture::new_hdr_procedural(o, 512, 256);
+        }
         o.textures.push_back(env);
     }
     o.lights.push_back(Light::make_infinite_light(o, nullptr, 1, 0));
@@ -362,10 +369,17 @@ static bool teapot_hdr(const PresetParams& p, FlatScene& out, std::string& err) 
     Camera camera = Camera::create(from, to, up, p.aspect_ratio, 35. / 2., 0.0, 10.);
     const std::string root = (p.mesh_path && p.mesh_path[0]) ? std::string(p.mesh_path) : std::string();
     {
+        // (a MISSING envmap.hdr is replaced by the procedural environment; one that is there but does not decode is an
+        // error -- the reference panics on it, material.rs:632-640 -- not a silent stand-in)
         rt_texture env;
         std::string e2;
-        if (root.empty() || !Texture::new_hdr(o, root + "/textures/envmap.hdr", env, e2))
+        if (root.empty() || !Texture::new_hdr(o, root + "/textures/envmap.hdr", env, e2)) {
+            if (!root.empty() && e2.rfind("Unable to open file", 0) != 0) {
+                err = e2;
+                return false;
+            }
             env = Texture::new_hdr_procedural(o, 512, 256);
+        }
         o.textures.push_back(env);
     }
     o.lights.push_back(Light::make_infinite_light(o, nullptr, 1, 0));

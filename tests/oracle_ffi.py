@@ -10,7 +10,8 @@ import numpy as np
 from rustraytracer_amd import _ffi as F
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(ROOT, "oracle", "liboracle.so")
+# RT_ORACLE_LIB: another build of the same checker (tests/test_host_sanitizers.py loads oracle/liboracle_asan.so)
+LIB_PATH = os.environ.get("RT_ORACLE_LIB") or os.path.join(ROOT, "oracle", "liboracle.so")
 
 EXHAUSTIVE, ORDERED, BRUTE = 0, 1, 2
 
