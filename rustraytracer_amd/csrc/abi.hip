@@ -64,7 +64,8 @@ struct Lane {
     uint32_t pool_cls = 0;  // class lists the pool was laid out for
     PathState st[2] = {};
     uint32_t* queue[2] = {nullptr, nullptr};
-    uint32_t* hitw = nullptr;  // the extension rays' hit words, by queue position (k_trace -> k_classify)
+    uint32_t* hitw = nullptr;  // the extension rays' hit words, by queue position (k_trace -> k_classify_*)
+    uint32_t* cls_tab = nullptr;  // k_classify_*: [kMaxCls][kClassifyWavesMax] per-wave counts, then list offsets
     Lists lists{};          // class lists + fold lists (scene_dev.h)
     uint32_t slot_cap = 0;  // records per pool = capacity + room for the unused ends of the waves' chunks
     uint32_t q_cap = 0;     // entries per ray queue
@@ -162,7 +163,9 @@ static void pool_layout(uint32_t cap, uint32_t n_cls, size_t& slots, size_t& qn,
     // of a launch's entries per kernel (kernels.hip: pick_chunk), summed generously
     slots = (size_t)cap + cap / 8 + 65536;
     qn = 3 * slots;
-    bytes = slots * (2 * (size_t)kRecBytes + 2 * sizeof(uint32_t)) + 3 * qn * sizeof(uint32_t) + (size_t)n_cls * slots * sizeof(ListEnt) + 4096;
+    // per slot and pool: the 256-B record + 12 ray words + 2 result words; 2 fold lists; per queue entry: 2 queues + hit words
+    bytes = slots * (2 * ((size_t)kRecBytes + 12 * 8 + 2 * 4) + 2 * sizeof(uint32_t)) + 3 * qn * sizeof(uint32_t) +
+            (size_t)n_cls * slots * sizeof(ListEnt) + 4096;
 }
 
 static int ensure_lane_capacity(rt_context* c, Lane& ln, uint32_t cap, uint32_t n_cls) {
@@ -189,8 +192,16 @@ static int ensure_lane_capacity(rt_context* c, Lane& ln, uint32_t cap, uint32_t 
     ln.pool = slab;
     char* p = (char*)ln.pool;
     for (int b = 0; b < 2; b++) {
-        ln.st[b].rec = p;
+        PathState& st = ln.st[b];
+        st.rec = p;
         p += slots * kRecBytes;
+        double** dptrs[] = {&st.ox, &st.oy, &st.oz, &st.dx, &st.dy, &st.dz, &st.spx, &st.spy, &st.spz, &st.pdx, &st.pdy, &st.pdz};
+        for (auto dp : dptrs) {
+            *dp = (double*)p;
+            p += slots * 8;
+        }
+        st.sh_prim = (int32_t*)p; p += slots * 4;
+        st.pr_prim = (int32_t*)p; p += slots * 4;
     }
     ln.lists.ent = (ListEnt*)p; p += (size_t)n_cls * slots * sizeof(ListEnt);
     ln.queue[0] = (uint32_t*)p; p += qn * sizeof(uint32_t);
@@ -290,6 +301,7 @@ static int context_init(rt_context* c) {
         std::memset(ln.mirror_h, 0, sizeof(MirrorEntry) * kRing);
         HIP_TRY(hipHostGetDevicePointer((void**)&ln.mirror_d, ln.mirror_h, 0));
         HIP_TRY(hipMalloc((void**)&ln.ctl, sizeof(Ctl)));
+        HIP_TRY(hipMalloc((void**)&ln.cls_tab, sizeof(uint32_t) * kMaxCls * 8192));
     }
     HIP_TRY(hipMalloc((void**)&c->stats, sizeof(DevStats) * kStatShards));
     HIP_TRY(hipMalloc((void**)&c->batch, sizeof(BatchCtl)));
@@ -312,6 +324,7 @@ int rt_context_destroy(rt_context* c) {
         for (auto ev : ln.events) (void)hipEventDestroy(ev);
         if (ln.pool) (void)hipFree(ln.pool);
         if (ln.ctl) (void)hipFree(ln.ctl);
+        if (ln.cls_tab) (void)hipFree(ln.cls_tab);
         if (ln.mirror_h) (void)hipHostFree(ln.mirror_h);
         if (ln.stream) (void)hipStreamDestroy(ln.stream);
     }
@@ -1084,9 +1097,15 @@ static int run_lane(RenderJob& job, int lane_id) {
         hipLaunchKernelGGL(trace_kernel(job.count_trav, job.s->dev.simple_others != 0, job.f32_trace), dim3(tblocks), dim3(256), 0, stream,
                            job.s->dev, ln.st[it & 1], ln.queue[it & 1], ln.ctl, (uint32_t)it, c->stats, c->tune,
                            no_mirror ? nullptr : ln.mirror_d, seq, c->batch, job.batch_total, ln.hitw);
-        // the traced paths to the lists of their vertex classes (a streaming pass over the queue)
-        hipLaunchKernelGGL(rtk::kernel_table().classify, dim3(std::min((3u * bound_active + 255u) / 256u + 1u, (uint32_t)c->num_cus * 8u)), dim3(256), 0,
-                           stream, ln.queue[it & 1], ln.hitw, ln.ctl, (uint32_t)it, ln.lists);
+        // the traced paths to the lists of their vertex classes: a counting sort over the queue (count, scan, scatter)
+        {
+            const uint32_t cblocks = std::min((3u * bound_active + 255u) / 256u + 1u, std::min((uint32_t)c->num_cus * 8u, 8192u / 4u));
+            hipLaunchKernelGGL(rtk::kernel_table().classify_count, dim3(cblocks), dim3(256), 0, stream, ln.queue[it & 1], ln.hitw, ln.ctl,
+                               (uint32_t)it, ln.cls_tab);
+            hipLaunchKernelGGL(rtk::kernel_table().classify_scan, dim3(1), dim3(1024), 0, stream, ln.cls_tab, cblocks * 4u, ln.ctl, (uint32_t)it);
+            hipLaunchKernelGGL(rtk::kernel_table().classify_scatter, dim3(cblocks), dim3(256), 0, stream, ln.queue[it & 1], ln.hitw, ln.st[it & 1],
+                               ln.ctl, (uint32_t)it, ln.cls_tab, ln.lists);
+        }
         if (!no_ev) {
             LANE_TRY(hipEventRecord(b, stream));
             ln.trace_ev.emplace_back(a, b);
@@ -1625,33 +1644,36 @@ __global__ __launch_bounds__(256) void k_wf_setup(const rt_ray* __restrict__ ray
     }
     if (i >= n) return;
     const rt_ray r = rays[i];
-    // (the fast mode keeps binary32 values in the low half of each word of a record, kernels.hip: w2r / r2w)
-    unsigned long long* w = reinterpret_cast<unsigned long long*>(st.rec + (size_t)i * kRecBytes);
-    auto put3 = [&](int at, const double* v) {
-        for (int k = 0; k < 3; k++)
-            w[at + k] = f32 ? (unsigned long long)__float_as_uint((float)v[k]) : (unsigned long long)__double_as_longlong(v[k]);
+    // (the fast mode keeps binary32 values in the low half of each element of the ray arrays, kernels.hip: ld3 / st3)
+    auto put = [&](double* a, double v) {
+        reinterpret_cast<unsigned long long*>(a)[i] = f32 ? (unsigned long long)__float_as_uint((float)v) : (unsigned long long)__double_as_longlong(v);
     };
-    put3(kWO, r.origin);
+    put(st.ox, r.origin[0]); put(st.oy, r.origin[1]); put(st.oz, r.origin[2]);
     // the three ray kinds of the render read their direction from different fields: spread the rays over two of them
     // (an extension ray and a probe ray are both traced on [SMALL, inf) -- a shadow ray is not a free-form ray)
     if (i & 1u) {
-        put3(kWPd, r.dir);
+        put(st.pdx, r.dir[0]); put(st.pdy, r.dir[1]); put(st.pdz, r.dir[2]);
         queue[i] = i | (kRayProbe << 30);
     } else {
-        put3(kWD, r.dir);
+        put(st.dx, r.dir[0]); put(st.dy, r.dir[1]); put(st.dz, r.dir[2]);
         queue[i] = i | (kRayExt << 30);
     }
-    int32_t* res = reinterpret_cast<int32_t*>(w + kWRes);  // {sh_prim, pr_prim}, {hit_prim, hit word}
-    res[1] = -2;
-    res[2] = -2;
+    st.pr_prim[i] = -2;
 }
 __global__ __launch_bounds__(256) void k_wf_collect(DevScene sc, const rt_ray* __restrict__ rays, uint32_t n, PathState st,
-                                                    rt_hit* hits) {
+                                                    const uint32_t* __restrict__ hitw, rt_hit* hits) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const rt_ray r = rays[i];
-    const int32_t* res = reinterpret_cast<const int32_t*>(st.rec + (size_t)i * kRecBytes + 8u * kWRes);
-    const int32_t prim = (i & 1u) ? res[1] : res[2];
+    // (the queue position of ray i is i: an extension ray's hit word is hitw[i] -- the leaf slot of a triangle, the
+    // primitive index of a sphere / rect, 0 = miss; a probe ray's result is the primitive itself)
+    int32_t prim;
+    if (i & 1u) {
+        prim = st.pr_prim[i];
+    } else {
+        const uint32_t hw = hitw[i];
+        prim = hw == 0u ? -1 : (int32_t)((hw & kLeafOther) ? (hw & kIdxMask) : (sc.leaf_prim[hw & kIdxMask] & kIdxMask));
+    }
     rt_hit h;
     h.prim = prim;
     h.t = kInf;
@@ -1707,10 +1729,9 @@ int rt_intersect_batch_ex(rt_context* c, rt_scene* s, const rt_ray* rays, uint64
             const unsigned tblocks = std::max(1u, std::min(blocks, (unsigned)(c->num_cus * std::max(1, occ))));
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(k_wf_setup, dim3(blocks), dim3(256), 0, c->stream, d_rays, (uint32_t)n, ln.st[0], ln.queue[0], ln.ctl, f32 ? 1 : 0);
-                // (no hit-word array: the extension rays' results go into their records, kernels.hip: k_trace)
                 hipLaunchKernelGGL(tk, dim3(tblocks), dim3(256), 0, c->stream, s->dev, ln.st[0], ln.queue[0], ln.ctl, 0u, c->stats,
-                                   c->tune, (MirrorEntry*)nullptr, 0u, c->batch, 0ull, (uint32_t*)nullptr);
-                hipLaunchKernelGGL(k_wf_collect, dim3(blocks), dim3(256), 0, c->stream, s->dev, d_rays, (uint32_t)n, ln.st[0], d_hits);
+                                   c->tune, (MirrorEntry*)nullptr, 0u, c->batch, 0ull, ln.hitw);
+                hipLaunchKernelGGL(k_wf_collect, dim3(blocks), dim3(256), 0, c->stream, s->dev, d_rays, (uint32_t)n, ln.st[0], ln.hitw, d_hits);
                 e = hipGetLastError();
             }
         }

@@ -17,8 +17,9 @@
 //            (integrator.rs:375-445), and writes survivors and their rays to the next pool / queue.
 //            Every wave of a class kernel runs ONE class over the whole launch (round 4; rounds 1-3 dealt
 //            a block's 256 consecutive slots to its waves by class).
-// Path state: one 256-B record per slot (scene_dev.h), two pools that ping-pong per bounce: a class kernel
-// reads record `slot` of X[it&1] and writes the survivor to a freshly allocated slot of X[(it+1)&1].
+// Path state (scene_dev.h): ray arrays for the traversal kernel + one 256-B record per slot for the shading kernels, two
+// pools that ping-pong per bounce: a class kernel reads record `slot` of X[it&1] and writes the survivor to a freshly
+// allocated slot of X[(it+1)&1].  Records move as whole 128-B lines, eight lanes per line, through LDS.
 // Waves are independent: output slots, queue entries and list entries come from per-wave CHUNKS of the
 // shared counters (one scalar atomic per chunk, no block barrier anywhere); the unused end of a wave's last
 // chunk is filled with null entries.  A retired path drops its radiance into lfinal[orig].
@@ -49,6 +50,15 @@ RTD rt_w r2w(double v) { return (rt_w)__float_as_uint(v); }
 RTD double w2r(rt_w w) { return __longlong_as_double((long long)w); }
 RTD rt_w r2w(double v) { return (rt_w)__double_as_longlong(v); }
 #endif
+// the ray arrays (one f64-sized element per slot; fast mode: the low half)
+RTD D3 ld3(const f64_t* x, const f64_t* y, const f64_t* z, uint32_t i) {
+    return d3(w2r(reinterpret_cast<const rt_w*>(x)[i]), w2r(reinterpret_cast<const rt_w*>(y)[i]), w2r(reinterpret_cast<const rt_w*>(z)[i]));
+}
+RTD void st3(f64_t* x, f64_t* y, f64_t* z, uint32_t i, D3 v) {
+    reinterpret_cast<rt_w*>(x)[i] = r2w(v.x);
+    reinterpret_cast<rt_w*>(y)[i] = r2w(v.y);
+    reinterpret_cast<rt_w*>(z)[i] = r2w(v.z);
+}
 RTD rt_w* rec_words(const PathState& st, uint32_t slot) { return reinterpret_cast<rt_w*>(st.rec + (size_t)slot * kRecBytes); }
 // a vec3 at word W: one aligned pair and one word, whichever way round W's parity puts them
 template <int W>
@@ -103,12 +113,22 @@ RTD void st_beta_l(rt_w* r, D3 beta, D3 l) {
     q.x = 0ull; q.y = 0ull;
     *reinterpret_cast<rt_w2*>(r + 14) = q;
 }
-// ---- whole-line stores of line 0.  A lane that writes its own record sends eight 16-B stores to a line of its own: 64
-// partly written lines per instruction (k_generate ran at 2.8 TB/s that way).  Instead every lane of a wave deposits its
-// line in LDS (pitch 9 pairs: conflict-free) and the wave writes the lines together, eight lanes per 128-B line.
+// ---- records move as WHOLE LINES, eight lanes per 128-B line.  A lane that touches its own record with eight 16-B
+// loads or stores makes eight L2 requests for one line, and the chip serves 50-75 G requests a second whatever their
+// size (tools/ubench_partial_write.hip: own-line 128-B writes 9.5 G lines/s, eight lanes per line 37.9 G lines/s).  So a
+// wave's 64 lines go through LDS: every lane deposits (or collects) its line there, pitch 9 pairs = conflict-free, and
+// the wave moves the lines between LDS and HBM together.  All 64 lanes must call stage_flush / stage_fetch (wave-uniform
+// control flow); a slot of kNullEntry at a rank = no line there.
 constexpr int kStagePitch = 9;                      // pairs per staged line (8 + 1 pad)
 constexpr int kStageWave = 64 * kStagePitch + 16;   // pairs per wave: 64 lines + their slots (64 x 4 B)
-RTD void stage_line(rt_w2* s, uint32_t rank, uint32_t slot, D3 o, D3 d, uint64_t rng, uint32_t orig, uint32_t flags, D3 beta, D3 l) {
+RTD uint32_t* stage_slots(rt_w2* s) { return reinterpret_cast<uint32_t*>(s + 64 * kStagePitch); }
+RTD void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// line 0 of a record: o, d, rng, {orig, flags}, beta, L, two spare words
+RTD void stage_line0(rt_w2* s, uint32_t rank, uint32_t slot, D3 o, D3 d, uint64_t rng, uint32_t orig, uint32_t flags, D3 beta, D3 l) {
     rt_w2* q = s + rank * kStagePitch;
     rt_w2 v;
     v.x = r2w(o.x); v.y = r2w(o.y); q[0] = v;
@@ -119,25 +139,61 @@ RTD void stage_line(rt_w2* s, uint32_t rank, uint32_t slot, D3 o, D3 d, uint64_t
     v.x = r2w(beta.z); v.y = r2w(l.x); q[5] = v;
     v.x = r2w(l.y); v.y = r2w(l.z); q[6] = v;
     v.x = 0ull; v.y = 0ull; q[7] = v;
-    reinterpret_cast<uint32_t*>(s + 64 * kStagePitch)[rank] = slot;
+    stage_slots(s)[rank] = slot;
 }
-// lines 0 .. cnt-1 of the wave's staging area go to their records (a slot of kNullEntry: nothing staged at that rank)
-RTD void stage_flush(rt_w2* s, const PathState& st, uint32_t cnt) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+// line 1: the pending direct-light terms A, Q, K
+RTD void stage_line1(rt_w2* s, uint32_t rank, uint32_t slot, D3 a, D3 q3, D3 k) {
+    rt_w2* q = s + rank * kStagePitch;
+    rt_w2 v;
+    v.x = r2w(a.x); v.y = r2w(a.y); q[0] = v;
+    v.x = r2w(a.z); v.y = r2w(q3.x); q[1] = v;
+    v.x = r2w(q3.y); v.y = r2w(q3.z); q[2] = v;
+    v.x = r2w(k.x); v.y = r2w(k.y); q[3] = v;
+    v.x = r2w(k.z); v.y = 0ull; q[4] = v;
+    v.x = 0ull; q[5] = v; q[6] = v; q[7] = v;
+    stage_slots(s)[rank] = slot;
+}
+// lines 0 .. cnt-1 of the wave's staging area go to line `line` of their records
+RTD void stage_flush(rt_w2* s, const PathState& st, uint32_t cnt, uint32_t line) {
+    wave_sync_lds();
     const uint32_t lane = threadIdx.x & 63u, part = lane & 7u;
-    const uint32_t* slots = reinterpret_cast<const uint32_t*>(s + 64 * kStagePitch);
+    const uint32_t* slots = stage_slots(s);
     for (uint32_t j0 = 0; j0 < cnt; j0 += 8u) {
         const uint32_t j = j0 + (lane >> 3);
         if (j < cnt) {
             const uint32_t slot = slots[j];
-            if (slot != kNullEntry) reinterpret_cast<rt_w2*>(st.rec + (size_t)slot * kRecBytes)[part] = s[j * kStagePitch + part];
+            if (slot != kNullEntry) reinterpret_cast<rt_w2*>(st.rec + (size_t)slot * kRecBytes)[line * 8u + part] = s[j * kStagePitch + part];
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();  // (the area is reused by the wave's next group)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    wave_sync_lds();  // (the area is reused)
+}
+// the reverse: line `line` of record `slot` (kNullEntry: none) of every lane arrives at that lane's rank = lane
+RTD void stage_fetch(rt_w2* s, const PathState& st, uint32_t slot, uint32_t line) {
+    const uint32_t lane = threadIdx.x & 63u, part = lane & 7u, sub = lane >> 3;
+    uint32_t* slots = stage_slots(s);
+    slots[lane] = slot;
+    wave_sync_lds();
+    // eight rounds of eight lines; the loads of all rounds are in flight together.  (Written out with scalars: the same
+    // code with small arrays and unrolled loops made the register allocator spill 1500 values in the class kernels.)
+    const char* base = st.rec + (size_t)(line * 8u + part) * 16u;
+    const uint32_t s0 = slots[sub], s1 = slots[8 + sub], s2 = slots[16 + sub], s3 = slots[24 + sub];
+    const uint32_t s4 = slots[32 + sub], s5 = slots[40 + sub], s6 = slots[48 + sub], s7 = slots[56 + sub];
+    rt_w2 z;
+    z.x = 0ull;
+    z.y = 0ull;
+#define RT_FETCH(v, sj) const rt_w2 v = sj != kNullEntry ? *reinterpret_cast<const rt_w2*>(base + (size_t)sj * kRecBytes) : z;
+    RT_FETCH(v0, s0) RT_FETCH(v1, s1) RT_FETCH(v2, s2) RT_FETCH(v3, s3) RT_FETCH(v4, s4) RT_FETCH(v5, s5) RT_FETCH(v6, s6) RT_FETCH(v7, s7)
+#undef RT_FETCH
+    rt_w2* row = s + sub * kStagePitch + part;
+    row[0 * 8 * kStagePitch] = v0;
+    row[1 * 8 * kStagePitch] = v1;
+    row[2 * 8 * kStagePitch] = v2;
+    row[3 * 8 * kStagePitch] = v3;
+    row[4 * 8 * kStagePitch] = v4;
+    row[5 * 8 * kStagePitch] = v5;
+    row[6 * 8 * kStagePitch] = v6;
+    row[7 * 8 * kStagePitch] = v7;
+    wave_sync_lds();
 }
 // a record's pairs in registers (the fields a kernel wants are fetched up front, independent of each other)
 struct RecRegs {
@@ -275,11 +331,13 @@ __global__ __launch_bounds__(256) void k_generate(PathState st, rt_camera cam, C
         const D3 dir = to - origin;
         (void)rng_next(rng);  // rand_range(t0, t1)
         // line 0 of the record in full: o, d, rng, {orig, flags}, beta = 1, L = 0 (whole-line stores, see stage_line)
-        stage_line(s_stage[wave], lane, slot, origin + offset, dir - offset, rng, g, 0u, white(), black());
+        stage_line0(s_stage[wave], lane, slot, origin + offset, dir - offset, rng, g, 0u, white(), black());
+        st3(st.ox, st.oy, st.oz, slot, origin + offset);  // (the ray itself, where the traversal kernel reads it)
+        st3(st.dx, st.dy, st.dz, slot, dir - offset);
         queue[ctl->gen_q + idx] = slot | (kRayExt << 30);
     }
     const uint32_t left = wave_first < n_gen ? n_gen - wave_first : 0u;
-    stage_flush(s_stage[wave], st, left < 64u ? left : 64u);
+    stage_flush(s_stage[wave], st, left < 64u ? left : 64u, 0u);
 }
 #endif  // RT_KERNELS_CORE
 
@@ -295,11 +353,11 @@ __global__ __launch_bounds__(256) void k_generate(PathState st, rt_camera cam, C
 //   * Every wave step is EITHER a node step OR a single-primitive step, whichever more lanes are
 //     waiting for (majority scheduling): the wave never runs the primitive code for the sake of a few
 //     lanes while the rest are walking the tree, and vice versa.
-//   * Results: a shadow / probe ray writes the primitive it found into its path's record; an extension ray writes its
-//     hit word (scene_dev.h) at its QUEUE position (hitw[]: neighbouring lanes, neighbouring words), from where k_classify
-//     deals the paths to the lists of their vertex classes.  (Appending to the class lists here -- a cursor per class, a
-//     ballot per class and refill round -- was measured: +10 % on every launch of this kernel, camera rays included.)
-//     hitw == null (rt_intersect_batch_ex): the extension result goes into the record as well.
+//   * Results: a shadow / probe ray writes the primitive it found at its path's slot (sh_prim / pr_prim); an extension
+//     ray writes its hit word (scene_dev.h) at its QUEUE position (hitw[]: neighbouring lanes, neighbouring words), from
+//     where k_classify deals the paths to the lists of their vertex classes.  (Appending to the class lists here -- a
+//     cursor per class, a ballot per class and refill round -- was measured: +10 % on every launch of this kernel, camera
+//     rays included; so was reading the rays out of the 256-B records, one 16-B request per lane and load: +5-10 %.)
 // Every wave leaves the loop once the queue is exhausted and its own lanes are done.
 template <bool COUNT, bool SIMPLE>
 __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, PathState st, const uint32_t* __restrict__ queue,
@@ -326,14 +384,9 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
             const uint32_t e = i < n ? queue[i] : kNullEntry;
             const uint32_t slot = e & kSlotMask, kind = e >> 30;
             const bool ext = kind == kRayExt;
-            if (ext) {
-                if (hitw)
-                    hitw[i] = 0u;
-                else
-                    reinterpret_cast<int32_t*>(rec_words(st, slot) + kWHit)[0] = -1;
-            }
-            if (kind == kRayShadow) reinterpret_cast<int32_t*>(rec_words(st, slot) + kWRes)[0] = -1;
-            if (kind == kRayProbe) reinterpret_cast<int32_t*>(rec_words(st, slot) + kWRes)[1] = -1;
+            if (ext) hitw[i] = 0u;
+            if (kind == kRayShadow) st.sh_prim[slot] = -1;
+            if (kind == kRayProbe) st.pr_prim[slot] = -1;
         }
         return;
     }
@@ -392,19 +445,9 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
         if (n_idle >= tune.refill_lanes || exhausted) {
             const uint32_t slot = slot_kind & kSlotMask, kind = slot_kind >> 30;
             const bool wb_ext = wb && kind == kRayExt;
-            if (wb_ext) {
-                const uint32_t hw = tv.best_prim < 0 ? 0u : hit_word(tv.best_prim, tv.best_slot);
-                if (hitw) {
-                    hitw[q_idx] = hw;
-                } else {
-                    int2 h;
-                    h.x = tv.best_prim;
-                    h.y = (int)hw;
-                    *reinterpret_cast<int2*>(rec_words(st, slot) + kWHit) = h;
-                }
-            }
-            if (wb && kind == kRayShadow) reinterpret_cast<int32_t*>(rec_words(st, slot) + kWRes)[0] = tv.best_prim;
-            if (wb && kind == kRayProbe) reinterpret_cast<int32_t*>(rec_words(st, slot) + kWRes)[1] = tv.best_prim;
+            if (wb_ext) hitw[q_idx] = tv.best_prim < 0 ? 0u : hit_word(tv.best_prim, tv.best_slot);
+            if (wb && kind == kRayShadow) st.sh_prim[slot] = tv.best_prim;
+            if (wb && kind == kRayProbe) st.pr_prim[slot] = tv.best_prim;
             wb = false;
         }
         if (!exhausted && (n_idle >= tune.refill_lanes)) {
@@ -461,20 +504,17 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
                 // (an entry of kind kRayNone is the unused end of a shading wave's queue chunk: nothing to trace)
                 if (!has_ray && my < take && (e >> 30) != kRayNone) {
                     const uint32_t slot = e & kSlotMask, kind = e >> 30;
-                    const rt_w* r = rec_words(st, slot);
-                    const rt_w2 p0 = *reinterpret_cast<const rt_w2*>(r), p1 = *reinterpret_cast<const rt_w2*>(r + 2);
-                    D3 o = d3(w2r(p0.x), w2r(p0.y), w2r(p1.x));
+                    D3 o = ld3(st.ox, st.oy, st.oz, slot);
                     D3 d;
                     double tmin = kSmall;
                     if (kind == kRayExt) {
-                        const rt_w2 p2 = *reinterpret_cast<const rt_w2*>(r + 4);
-                        d = d3(w2r(p1.y), w2r(p2.x), w2r(p2.y));
+                        d = ld3(st.dx, st.dy, st.dz, slot);
                     } else if (kind == kRayShadow) {  // Visibility::unoccluded, hittable.rs:25-32
-                        d = ld3w<kWSp>(r) - o;
+                        d = ld3(st.spx, st.spy, st.spz, slot) - o;
                         o = o + d * kSmall;
                         tmin = 0.0;
                     } else {
-                        d = ld3w<kWPd>(r);
+                        d = ld3(st.pdx, st.pdy, st.pdz, slot);
                     }
                     trav_init(tv, sc, o, d, tmin, kInf);
                     slot_kind = e;
@@ -566,27 +606,32 @@ __global__ __launch_bounds__(256) void k_intersect_batch(DevScene sc, const rt_r
 
 // ------------------------------------------------------------------ classify
 // Deals the paths whose extension ray k_trace has just traced to the lists of their vertex classes (scene_dev.h): a
-// streaming pass over the queue and the hit words, 8 + 8 bytes per path.  A wave takes a contiguous span of the queue, so
-// a list chunk holds neighbouring paths in queue order; per class a cursor (SGPRs, the class loop is unrolled) hands out
-// list entries from chunks of the class counter.
-template <int DUMMY>
-__global__ __launch_bounds__(256) void k_classify(const uint32_t* __restrict__ queue, const uint32_t* __restrict__ hitw, Ctl* ctl,
-                                                  uint32_t it_abs, Lists lists) {
-    const uint32_t n = ctl->n_rays[it_abs % kRing];
+// streaming counting sort over the queue and the hit words, in three small launches -- count (every wave: the classes of
+// its contiguous span of the queue), scan (one block: where every wave's part of every list starts), scatter (the
+// entries).  No atomic (a first version appended through per-wave chunks of the class counters: 150 k same-address
+// atomics per launch, 112 ms of a C4 frame -- the pass ran at the atomic ceiling, not at its 32 B per path), no unused
+// entries, and the lists keep the queue's order, i.e. the order of the paths: what an XCD traces and shades stays one
+// moving window of the scene.  A list entry carries everything the traversal found for the path -- hit word, and the
+// shadow / probe result of a path with pending light terms -- so the shading kernels read no result array.
+constexpr uint32_t kClassifyWavesMax = 8192;  // waves of the count / scatter launches (the scan block handles this many)
+RTD uint32_t classify_span(uint32_t n, uint32_t n_waves, uint32_t wave_g, uint32_t& g_end) {
     const uint32_t n_groups = (n + 63u) / 64u;
+    const uint32_t per_wave = (n_groups + n_waves - 1u) / n_waves;
+    const uint32_t g_first = wave_g * per_wave < n_groups ? wave_g * per_wave : n_groups;
+    g_end = g_first + per_wave < n_groups ? g_first + per_wave : n_groups;
+    return g_first;
+}
+template <int DUMMY>
+__global__ __launch_bounds__(256) void k_classify_count(const uint32_t* __restrict__ queue, const uint32_t* __restrict__ hitw, const Ctl* ctl,
+                                                        uint32_t it_abs, uint32_t* __restrict__ counts /* [kMaxCls][n_waves] */) {
+    const uint32_t n = ctl->n_rays[it_abs % kRing];
     const uint32_t lane = threadIdx.x & 63u, n_waves = gridDim.x * 4u;
     const uint32_t wave_g = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t per_wave = (n_groups + n_waves - 1u) / n_waves;
-    const uint32_t g_first = wave_g * per_wave, g_end = g_first + per_wave < n_groups ? g_first + per_wave : n_groups;
-    if (g_first >= g_end) return;
-    const uint32_t chunk = pick_chunk(n, n_waves < n_groups ? n_waves : n_groups);
-    uint32_t* const counters = &ctl->cls_count[it_abs & 3u][0][0];
-    Cursor ccur[kMaxCls];
+    uint32_t g_end;
+    const uint32_t g_first = classify_span(n, n_waves, wave_g, g_end);
+    uint32_t cnt[kMaxCls];
 #pragma unroll
-    for (int c = 0; c < kMaxCls; c++) ccur[c] = Cursor{0u, 0u};
-    const unsigned long long below = (1ull << lane) - 1ull;
-    // four groups per round: their eight loads are in flight together (one group at a time, the pass ran at 0.7 TB/s --
-    // 114 ms of a C4 frame -- on nothing but its own load latency)
+    for (int c = 0; c < kMaxCls; c++) cnt[c] = 0u;
     for (uint32_t g0 = g_first; g0 < g_end; g0 += 4u) {
         uint32_t e4[4], hw4[4];
 #pragma unroll
@@ -598,28 +643,92 @@ __global__ __launch_bounds__(256) void k_classify(const uint32_t* __restrict__ q
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
+            const uint32_t cls = (e4[u] >> 30) == kRayExt ? (hw4[u] >> kClsShift & (uint32_t)(kMaxCls - 1)) : (uint32_t)kMaxCls;
+#pragma unroll
+            for (int c = 0; c < kMaxCls; c++) cnt[c] += (uint32_t)__popcll(__ballot(cls == (uint32_t)c));
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < kMaxCls; c++) counts[(uint32_t)c * n_waves + wave_g] = cnt[c];
+    }
+}
+// one block of 1024 threads: exclusive prefix of every class's counts over the waves (in place), totals -> list lengths
+template <int DUMMY>
+__global__ __launch_bounds__(1024) void k_classify_scan(uint32_t* counts, uint32_t n_waves, Ctl* ctl, uint32_t it_abs) {
+    __shared__ uint32_t s_part[1024];
+    const uint32_t per = (n_waves + 1023u) / 1024u;  // <= 8
+    for (uint32_t c = 0; c < (uint32_t)kMaxCls; c++) {
+        uint32_t* row = counts + c * n_waves;
+        uint32_t v[8], sum = 0;
+        for (uint32_t k = 0; k < per; k++) {
+            const uint32_t i = threadIdx.x * per + k;
+            v[k] = i < n_waves ? row[i] : 0u;
+            sum += v[k];
+        }
+        s_part[threadIdx.x] = sum;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024u; d <<= 1) {  // Hillis-Steele over the 1024 partial sums
+            const uint32_t add = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0u;
+            __syncthreads();
+            s_part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        uint32_t run = threadIdx.x ? s_part[threadIdx.x - 1] : 0u;
+        for (uint32_t k = 0; k < per; k++) {
+            const uint32_t i = threadIdx.x * per + k;
+            if (i < n_waves) row[i] = run;
+            run += v[k];
+        }
+        if (threadIdx.x == 1023u) ctl->cls_count[it_abs & 3u][c][0] = s_part[1023];
+        __syncthreads();
+    }
+}
+template <int DUMMY>
+__global__ __launch_bounds__(256) void k_classify_scatter(const uint32_t* __restrict__ queue, const uint32_t* __restrict__ hitw, PathState st,
+                                                          const Ctl* ctl, uint32_t it_abs, const uint32_t* __restrict__ offsets, Lists lists) {
+    const uint32_t n = ctl->n_rays[it_abs % kRing];
+    const uint32_t lane = threadIdx.x & 63u, n_waves = gridDim.x * 4u;
+    const uint32_t wave_g = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t g_end;
+    const uint32_t g_first = classify_span(n, n_waves, wave_g, g_end);
+    if (g_first >= g_end) return;
+    uint32_t at[kMaxCls];
+#pragma unroll
+    for (int c = 0; c < kMaxCls; c++) at[c] = (uint32_t)c < lists.n_cls ? offsets[(uint32_t)c * n_waves + wave_g] : 0u;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    // four groups per round: their loads are in flight together
+    for (uint32_t g0 = g_first; g0 < g_end; g0 += 4u) {
+        uint32_t e4[4], hw4[4];
+        int32_t sh4[4], pr4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = (g0 + u) * 64u + lane;
+            const bool in = g0 + u < g_end && i < n;
+            e4[u] = in ? queue[i] : kNullEntry;
+            hw4[u] = in ? hitw[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {  // (consecutive entries are mostly consecutive slots: near-coalesced)
+            const bool pend = (e4[u] >> 30) == kRayExt && (e4[u] & kQPending);
+            sh4[u] = pend ? st.sh_prim[e4[u] & kSlotMask] : -1;
+            pr4[u] = pend ? st.pr_prim[e4[u] & kSlotMask] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
             const uint32_t e = e4[u], hw = hw4[u];
             const bool ext = (e >> 30) == kRayExt;
-            if (__ballot(ext) == 0ull) continue;
             const uint32_t cls = ext ? (hw >> kClsShift & (uint32_t)(kMaxCls - 1)) : (uint32_t)kMaxCls;
             const uint32_t slot_word = (e & kSlotMask) | ((e & kQPending) ? kEntPending : 0u);
 #pragma unroll
             for (int c = 0; c < kMaxCls; c++) {
-                if ((uint32_t)c >= lists.n_cls) break;
                 const bool mine = cls == (uint32_t)c;
                 const unsigned long long m = __ballot(mine);
-                if (m) {
-                    const uint32_t at = cursor_take(ccur[c], counters + c * 32, chunk, (uint32_t)__popcll(m), (uint32_t)__popcll(m & below));
-                    if (mine && at < lists.cap) lists.ent[(size_t)c * lists.cap + at] = ListEnt{slot_word, hw};
-                }
+                const uint32_t to = at[c] + (uint32_t)__popcll(m & below);
+                if (mine && to < lists.cap) lists.ent[(size_t)c * lists.cap + to] = ListEnt{slot_word, hw, sh4[u], pr4[u]};
+                at[c] += (uint32_t)__popcll(m);
             }
         }
-    }
-    if (chunk) {
-#pragma unroll
-        for (int c = 0; c < kMaxCls; c++)
-            for (uint32_t i = ccur[c].cur + lane; i < ccur[c].end; i += 64u)
-                if (i < lists.cap) lists.ent[(size_t)c * lists.cap + i] = ListEnt{kNullEntry, 0u};
     }
 }
 
@@ -628,9 +737,11 @@ __global__ __launch_bounds__(256) void k_classify(const uint32_t* __restrict__ q
 //   shade_a: fold the previous vertex's direct light (estimate_direct's two additions, using the R2/R3
 //            results), rebuild the record of the vertex the extension ray found, emitted-light rule.
 //   shade_b: BSDF, one-light NEE + MIS (integrator.rs:530-634), continuation sample, Russian roulette
-//            (integrator.rs:421-442); writes the survivor's state to record `os` of `out`.
-// The class kernels run them for one bounce of every path of their class; k_tail loops them per lane until the path
-// retires.  KIND (scene_dev.h: kKind*) says what kind of hit the caller's paths have, i.e. which record code is compiled in.
+//            (integrator.rs:421-442); returns the survivor's state (ShadeRes), its rays go to the ray arrays.
+// A class kernel runs them for one bounce of every path of its class in three phases per 64-path group: records in
+// (whole lines through the wave's LDS staging area: rec_fetch), compute (no barrier inside), records out (rec_store).
+// k_tail loops them per lane until the path retires and touches its records directly.  KIND (scene_dev.h: kKind*) says
+// what kind of hit the caller's paths have, i.e. which record code is compiled in.
 struct ShadeA {
     D3 L, o, d, beta;
     HitRec rec;
@@ -640,39 +751,41 @@ struct ShadeA {
     bool live, spec, will_shade;
 };
 
-// `hit` = the extension ray's hit word (scene_dev.h), `some` = it hit something; both ignored for a fold-only path.
-// `pending` = the path may carry pending light terms (its flags decide): line 1 of its record is fetched as well.
+// A path's record in registers.  rec_fetch: every lane of a wave calls it (class kernels) -- line 0 of all valid lanes'
+// records, and line 1 (the pending direct-light terms) of those whose list entry and flags say they carry any, arrive as
+// whole lines through the staging area.  rec_load: the same by the lane itself (k_tail).
+RTD bool rec_wants_line1(const RecRegs& R, bool valid, bool pending) {
+    return valid && pending && ((uint32_t)(R.p[3].y >> 32) & (kHasShadow | kHasProbe)) != 0u;
+}
+RTD void rec_fetch(rt_w2* stage, const PathState& in, uint32_t slot, bool valid, bool pending, RecRegs& R) {
+    const uint32_t lane = threadIdx.x & 63u;
+    stage_fetch(stage, in, valid ? slot : kNullEntry, 0u);
+#pragma unroll
+    for (int k = 0; k < 7; k++) R.p[k] = stage[lane * kStagePitch + k];
+    const bool fold = rec_wants_line1(R, valid, pending);
+    if (__ballot(fold)) {
+        wave_sync_lds();  // (every lane has read its line 0)
+        stage_fetch(stage, in, fold ? slot : kNullEntry, 1u);
+#pragma unroll
+        for (int k = 0; k < 5; k++) R.p[8 + k] = stage[lane * kStagePitch + k];
+    }
+    wave_sync_lds();  // (the area is free again)
+}
+RTD void rec_load(const PathState& in, uint32_t slot, bool pending, RecRegs& R) {
+    const rt_w2* rp = reinterpret_cast<const rt_w2*>(rec_words(in, slot));
+#pragma unroll
+    for (int k = 0; k < 7; k++) R.p[k] = rp[k];
+    if (rec_wants_line1(R, true, pending)) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) R.p[8 + k] = rp[8 + k];
+    }
+}
+
+// `R` = the path's record, `hit` = the extension ray's hit word (scene_dev.h), `some` = it hit something (both ignored for
+// a fold-only path), `sh`, `pp` = results of the path's shadow / probe ray, `pending` = it may carry pending light terms.
 template <int FEAT, int KIND>
-RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, uint32_t hit, bool some, bool pending, bool valid,
-                 uint32_t max_depth, ShadeA& a) {
-    // Every field of the record this function may need is fetched up front: the loads are independent, so they cost one
-    // memory latency instead of one per branch level below.  (A lane without a path reads record 0, which always
-    // exists.)  Line 0 always (kKindNone, without an environment: its second atom and the flags only); line 1 -- the
-    // pending direct-light terms -- only for paths whose list entry says they may carry any.
-    const rt_w* r = rec_words(in, valid ? slot : 0u);
-    const rt_w2* rp = reinterpret_cast<const rt_w2*>(r);
-    RecRegs R;
-    R.p[3] = rp[3];
-    R.p[4] = rp[4];
-    R.p[5] = rp[5];
-    R.p[6] = rp[6];
-    R.p[7] = rp[7];
-    if (KIND != kKindNone || ((FEAT & kFeatEnv) != 0)) {
-        R.p[0] = rp[0];
-        R.p[1] = rp[1];
-        R.p[2] = rp[2];
-    }
-    if (pending) {
-        if (KIND == kKindNone && !((FEAT & kFeatEnv) != 0)) {  // (the probe fold starts at o)
-            R.p[0] = rp[0];
-            R.p[1] = rp[1];
-        }
-        R.p[8] = rp[8];
-        R.p[9] = rp[9];
-        R.p[10] = rp[10];
-        R.p[11] = rp[11];
-        R.p[12] = rp[12];
-    }
+RTD void shade_a(const DevScene& sc, const PathState& in, const RecRegs& R, uint32_t slot, uint32_t hit, bool some, int32_t sh, int32_t pp,
+                 bool pending, bool valid, uint32_t max_depth, ShadeA& a) {
     a.rng = R.p[3].x;
     a.orig = (uint32_t)R.p[3].y;
     const uint32_t fl = valid ? (uint32_t)(R.p[3].y >> 32) : 0u;
@@ -680,22 +793,21 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, uint32_
     a.live = valid;
     a.L = black();
     a.o = black();
+    const bool fold = rec_wants_line1(R, valid, pending);
     if (a.live) {
         a.L = rec3<kWL>(R);
+        a.o = rec3<kWO>(R);
         // ---- fold the previous vertex's direct lighting
-        if (pending && (fl & (kHasShadow | kHasProbe))) {
-            a.o = rec3<kWO>(R);
+        if (fold) {
             const uint32_t light_idx = fl >> kLightShift;
             const rt_light& lt = sc.lights[light_idx];
             const bool infinite = ((FEAT & kFeatEnv) != 0) && lt.kind == RT_LIGHT_INFINITE;
             D3 ld = black();
             if (fl & kHasShadow) {
                 // Visibility::unoccluded(infinite): an area light must be the closest hit, the environment needs a miss
-                const int32_t sh = (int32_t)(uint32_t)R.p[7].x;
                 if (infinite ? sh < 0 : sh == (int32_t)lt.prim_index) ld = ld + rec3<kWA>(R);
             }
             if (fl & kHasProbe) {
-                const int32_t pp = (int32_t)(uint32_t)(R.p[7].x >> 32);
                 const D3 q_in = rec3<kWQ>(R);
                 if (infinite) {
                     // integrator.rs:617-630: an escaped probe sees light.le(ray), already folded into q by shade_b
@@ -703,7 +815,7 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, uint32_
                 } else if (pp >= 0) {
                     const int32_t li = sc.prims[pp].light_index;
                     if (li >= 0 && (uint32_t)li == light_idx) {
-                        const D3 pd = ld3w<kWPd>(r);
+                        const D3 pd = ld3(in.pdx, in.pdy, in.pdz, slot);
                         const rt_primitive& lpr = sc.prims[pp];
                         if (lpr.kind >= RT_PRIM_XY_RECT && lpr.xform_index < 0) {
                             // axis-aligned rect emitter: the record's normal faces the ray (set_front), so
@@ -737,11 +849,8 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, uint32_
     a.bounces = fl & kBounceMask;
     a.spec = (fl & kSpecular) != 0;
     if (active) {
-        if (KIND != kKindNone || ((FEAT & kFeatEnv) != 0)) {
-            if (KIND != kKindNone) a.o = rec3<kWO>(R);
-            a.d = rec3<kWD>(R);
-            a.beta = rec3<kWBeta>(R);
-        }
+        a.d = rec3<kWD>(R);
+        a.beta = rec3<kWBeta>(R);
         is_some = KIND != kKindNone && some;
         if (is_some) is_some = hit_record<KIND>(sc, hit, a.o, a.d, kSmall, kInf, a.rec);
         if (a.bounces == 0 || a.spec) {  // integrator.rs:396-411 (Q18)
@@ -757,20 +866,24 @@ RTD void shade_a(const DevScene& sc, const PathState& in, uint32_t slot, uint32_
     a.will_shade = active && is_some && a.bounces < max_depth;
 }
 
-struct ShadeOut {
+// what a shaded vertex leaves: the survivor's record fields (line 0: o = rec.p, d, rng, flags, beta, L; line 1 when it
+// has pending terms: A, Q, K = the beta it arrived with) and which rays it started
+struct ShadeRes {
+    D3 d, beta, pa, pq;
+    uint64_t rng;
+    uint32_t flags;
     bool emit_ext, emit_sh, emit_pr, keep;
 };
 
-// Precondition: a.will_shade.  `os` = slot of `out` reserved for this vertex.  `stage` (class kernels): the wave's staging
-// area, where line 0 of the survivor's record is deposited as line `rank` for the caller's stage_flush; null: stored here.
+// Precondition: a.will_shade.  `os` = slot of `out` reserved for this vertex: its rays (origin, extension direction,
+// shadow target, probe direction) are written to the ray arrays here, the record by the caller.
 template <int FEAT>
-RTD ShadeOut shade_b(const DevScene& sc, const PathState& out, uint32_t os, ShadeA& a, rt_w2* stage = nullptr, uint32_t rank = 0u) {
+RTD ShadeRes shade_b(const DevScene& sc, const PathState& out, uint32_t os, const ShadeA& a) {
     const HitRec& rec = a.rec;
     D3 beta = a.beta;
     uint32_t bounces = a.bounces;
     bool spec = a.spec;
     uint64_t rng = a.rng;
-    rt_w* ow = rec_words(out, os);
     // (locals are initialised even where every path that reads them assigns them first: inside the class kernels' loop an
     // undefined value is a register that stays allocated around the whole loop -- k_shade_cls<0, mesh> spilled 72 VGPRs
     // with `ShadeA a;` and 7 with `ShadeA a{};`)
@@ -778,6 +891,7 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& out, uint32_t os, Shad
     compute_scattering<FEAT>(sc, rec, bsdf);
     bool has_sh = false, has_pr = false;
     uint32_t light_num = 0;
+    D3 pa = black(), pq = black();
     // ---- uniform_sample_one_light / estimate_direct (integrator.rs:530-634)
     if (sc.n_lights > 0) {
         const double pick = rng_next(rng);
@@ -819,8 +933,8 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& out, uint32_t os, Shad
             if (!is_black(f)) {
                 has_sh = true;
                 const double weight = power_heuristic(1, light_pdf, 1, scattering_pdf);
-                st3w<kWA>(ow, cmul(f, color) * (weight / light_pdf));
-                st3w<kWSp>(ow, sp);
+                pa = cmul(f, color) * (weight / light_pdf);
+                st3(out.spx, out.spy, out.spz, os, sp);
             }
         }
         {
@@ -843,12 +957,11 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& out, uint32_t os, Shad
                     has_pr = true;
                     // the radiance an escaped probe would see is a function of its direction only: fold it in now
                     const D3 pcol = infinite ? infinite_le(sc, lt, wi2) : ltcolor;
-                    st3w<kWQ>(ow, is_black(pcol) ? black() : cmul(f2, pcol) * (weight / spdf));
-                    st3w<kWPd>(ow, wi2);
+                    pq = is_black(pcol) ? black() : cmul(f2, pcol) * (weight / spdf);
+                    st3(out.pdx, out.pdy, out.pdz, os, wi2);
                 }
             }
         }
-        if (has_sh || has_pr) st3w<kWK>(ow, beta);
     }
     // ---- continuation (integrator.rs:421-442)
     const D3 wo = -a.d;
@@ -870,26 +983,38 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& out, uint32_t os, Shad
         }
         bounces = bounces + 1;
     }
-    ShadeOut r;
+    ShadeRes r;
     r.emit_ext = cont;
     r.emit_sh = has_sh;
     r.emit_pr = has_pr;
     r.keep = cont || has_sh || has_pr;
-    const uint32_t flags = (bounces & kBounceMask) | (spec ? kSpecular : 0u) | (cont ? 0u : kFoldOnly) | (has_sh ? kHasShadow : 0u) |
-                           (has_pr ? kHasProbe : 0u) | (light_num << kLightShift);
-    // line 0 of the record in full (a fold-only path's d / beta are never read); origin = hit point (spawn_ray, Q4)
-    if (stage) {
-        if (r.keep)
-            stage_line(stage, rank, os, rec.p, wi, rng, a.orig, flags, beta, a.L);
-        else
-            reinterpret_cast<uint32_t*>(stage + 64 * kStagePitch)[rank] = kNullEntry;
-    } else if (r.keep) {
-        st3w<kWO>(ow, rec.p);
-        st3w<kWD>(ow, wi);
-        st_meta(ow, rng, a.orig, flags);
-        st_beta_l(ow, beta, a.L);
+    r.flags = (bounces & kBounceMask) | (spec ? kSpecular : 0u) | (cont ? 0u : kFoldOnly) | (has_sh ? kHasShadow : 0u) |
+              (has_pr ? kHasProbe : 0u) | (light_num << kLightShift);
+    r.d = wi;
+    r.beta = beta;
+    r.pa = pa;
+    r.pq = pq;
+    r.rng = rng;
+    // origin = hit point (spawn_ray, Q4); a fold-only path's d / beta are never read
+    if (r.keep) {
+        st3(out.ox, out.oy, out.oz, os, rec.p);
+        if (cont) st3(out.dx, out.dy, out.dz, os, wi);
     }
     return r;
+}
+// the survivor's record, written by the lane itself (k_tail)
+RTD void rec_store_direct(const PathState& out, uint32_t os, const ShadeA& a, const ShadeRes& r) {
+    if (!r.keep) return;
+    rt_w* ow = rec_words(out, os);
+    st3w<kWO>(ow, a.rec.p);
+    st3w<kWD>(ow, r.d);
+    st_meta(ow, r.rng, a.orig, r.flags);
+    st_beta_l(ow, r.beta, a.L);
+    if (r.emit_sh || r.emit_pr) {
+        st3w<kWA>(ow, r.pa);
+        st3w<kWQ>(ow, r.pq);
+        st3w<kWK>(ow, a.beta);
+    }
 }
 
 #ifndef RT_SHADE_WAVES
@@ -911,12 +1036,12 @@ RTD ShadeOut shade_b(const DevScene& sc, const PathState& out, uint32_t os, Shad
 #define RT_SHADE_BOUND(F) RT_SHADE_BOUND_RULE(F)
 #endif
 
-// One vertex class of one bounce (scene_dev.h): the paths of list `cls`, which k_trace filled with the extension rays
+// One vertex class of one bounce (scene_dev.h): the paths of list `cls`, which k_classify filled with the extension rays
 // that hit a primitive of that class.  FEAT = the shading features the class's materials need (so a class of glass does
 // not carry the microfacet code, nor a Lambertian floor the glass code), KIND = mesh slot / sphere-rect / generic record.
-// Persistent, barrier-free: wave w takes the 64-entry groups w, w + n_waves, ... of the list; output slots, queue entries
+// Persistent, barrier-free: a wave takes a contiguous span of the list in 64-entry groups; output slots, queue entries
 // (a chunk per ray kind, so a traversal wave's reservation is mostly one kind) and fold-list entries come from
-// per-wave chunks of the shared counters.
+// per-wave chunks of the shared counters; records move as whole lines through the wave's staging area in LDS.
 template <int FEAT, int KIND>
 __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade_cls(DevScene sc, PathState in, PathState out, Ctl* ctl, uint32_t it_abs,
                                                uint32_t max_depth, Lists lists, uint32_t cls, uint32_t* queue_out, uint32_t q_cap,
@@ -925,8 +1050,7 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade_cls(DevScen
     const uint32_t n = ctl->cls_count[it_abs & 3u][cls][0];
     const uint32_t n_groups = (n + 63u) / 64u;
     const uint32_t lane = threadIdx.x & 63u, n_waves = gridDim.x * (blockDim.x >> 6);
-    // (wave-uniform for the compiler too: the loop below and its cursors then live in SGPRs -- with a per-lane loop counter
-    // every cursor is a VGPR and the kernel spills 76-139 registers instead of 8-16)
+    // (wave-uniform for the compiler too: the loop below and its cursors then live in SGPRs)
     const uint32_t wave_g = blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // a contiguous span of the list per wave: its queue chunks then hold neighbouring paths in list (= queue) order
     const uint32_t per_wave = (n_groups + n_waves - 1u) / n_waves;
@@ -938,33 +1062,51 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade_cls(DevScen
     uint32_t* const c_slots = &ctl->n_active[itn];
     uint32_t* const c_rays = &ctl->n_rays[itn];
     uint32_t* const c_fold = &ctl->fold_count[(it_abs + 1u) & 3u][0];
-    __shared__ rt_w2 s_stage[4][kStageWave];  // whole-line stores of the survivors' records (stage_line)
+    __shared__ rt_w2 s_stage[4][kStageWave];
     rt_w2* const stage = s_stage[threadIdx.x >> 6];
     Cursor cs{0u, 0u}, cq0{0u, 0u}, cq1{0u, 0u}, cq2{0u, 0u}, cf{0u, 0u};
     uint32_t n_r1 = 0, n_r2 = 0, n_r3 = 0, n_v = 0;  // wave-uniform
     const unsigned long long below = (1ull << lane) - 1ull;
     for (uint32_t g = g_first; g < g_end; g++) {
         const uint32_t i = g * 64u + lane;
-        ListEnt e{kNullEntry, 0u};
+        ListEnt e{kNullEntry, 0u, -1, -1};
         if (i < n) e = ent[i];
-        const bool valid = e.slot != kNullEntry;  // (null: the unused end of a traversal wave's list chunk)
+        const bool valid = e.slot != kNullEntry;
+        // ---- records in
+        const bool pending = valid && (e.slot & kEntPending);
+        RecRegs R{};
+        rec_fetch(stage, in, e.slot & kSlotMask, valid, pending, R);
+        // ---- compute
         ShadeA a{};
-        shade_a<FEAT, KIND>(sc, in, e.slot & kSlotMask, e.hit, true, valid && (e.slot & kEntPending), valid, max_depth, a);
+        shade_a<FEAT, KIND>(sc, in, R, e.slot & kSlotMask, e.hit, true, e.sh, e.pr, pending, valid, max_depth, a);
         const unsigned long long m = __ballot(a.will_shade);
+        const uint32_t cnt = (uint32_t)__popcll(m), rank = (uint32_t)__popcll(m & below);
         uint32_t os = 0;
-        const uint32_t rank = (uint32_t)__popcll(m & below);
         if (m) {
-            os = cursor_take(cs, c_slots, chunk, (uint32_t)__popcll(m), rank);
-            n_v += (uint32_t)__popcll(m);
+            os = cursor_take(cs, c_slots, chunk, cnt, rank);
+            n_v += cnt;
         }
-        ShadeOut r{false, false, false, false};
-        if (a.will_shade) {
-            if (os < slot_cap)
-                r = shade_b<FEAT>(sc, out, os, a, stage, rank);
-            else
-                reinterpret_cast<uint32_t*>(stage + 64 * kStagePitch)[rank] = kNullEntry;
+        ShadeRes r{};
+        if (a.will_shade && os < slot_cap) r = shade_b<FEAT>(sc, out, os, a);
+        // ---- records out: line 0 of every survivor, line 1 of those with pending terms
+        if (m) {
+            if (a.will_shade) {
+                if (r.keep)
+                    stage_line0(stage, rank, os, a.rec.p, r.d, r.rng, a.orig, r.flags, r.beta, a.L);
+                else
+                    stage_slots(stage)[rank] = kNullEntry;
+            }
+            stage_flush(stage, out, cnt, 0u);
+            if (__ballot(r.emit_sh || r.emit_pr)) {
+                if (a.will_shade) {
+                    if (r.emit_sh || r.emit_pr)
+                        stage_line1(stage, rank, os, r.pa, r.pq, a.beta);
+                    else
+                        stage_slots(stage)[rank] = kNullEntry;
+                }
+                stage_flush(stage, out, cnt, 1u);
+            }
         }
-        if (m) stage_flush(stage, out, (uint32_t)__popcll(m));
         if (a.live && !r.keep) film_put(lf, a.orig, a.L);  // retired: its radiance goes to the film staging slot of (pixel, sample)
         // ---- rays of the next bounce, and the paths that only have light terms to fold
         const unsigned long long me = __ballot(r.emit_ext), ms = __ballot(r.emit_sh), mp = __ballot(r.emit_pr);
@@ -1003,29 +1145,44 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade_cls(DevScen
 }
 
 // The paths that end this bounce without a vertex to shade: list 0 (the extension ray escaped) and the fold list (no
-// extension ray, only pending light terms).  Fold, emitted light of the environment, film staging -- a few dozen
-// registers and, for most of them, 48 of the record's 256 bytes.
+// extension ray, only pending light terms; their shadow / probe results are read at their slots).  Fold, emitted light
+// of the environment, film staging -- a few dozen registers, one whole line of the record for most of them.
 template <int FEAT>
-__global__ __launch_bounds__(256) void k_shade_light(DevScene sc, PathState in, Ctl* ctl, uint32_t it_abs, uint32_t max_depth,
+__global__ __launch_bounds__(256, 4) void k_shade_light(DevScene sc, PathState in, Ctl* ctl, uint32_t it_abs, uint32_t max_depth,
                                                      Lists lists, f64_t* lf) {
     const uint32_t n0 = ctl->cls_count[it_abs & 3u][0][0], n1 = ctl->fold_count[it_abs & 3u][0];
     const uint32_t g0 = (n0 + 63u) / 64u, n_groups = g0 + (n1 + 63u) / 64u;
     const uint32_t lane = threadIdx.x & 63u, n_waves = gridDim.x * (blockDim.x >> 6);
     const uint32_t* fold_in = lists.fold[it_abs & 1u];
+    __shared__ rt_w2 s_stage[4][kStageWave];
+    rt_w2* const stage = s_stage[threadIdx.x >> 6];
     for (uint32_t g = blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); g < n_groups; g += n_waves) {
         uint32_t slot = kNullEntry;
-        bool pending = true;  // a fold-only path is nothing but pending terms
+        int32_t sh = -1, pr = -1;
+        bool pending = false;
         if (g < g0) {
             const uint32_t i = g * 64u + lane;
-            if (i < n0) slot = lists.ent[i].slot;
-            pending = (slot & kEntPending) != 0u;
+            if (i < n0) {
+                const ListEnt e = lists.ent[i];
+                slot = e.slot;
+                sh = e.sh;
+                pr = e.pr;
+                pending = slot != kNullEntry && (slot & kEntPending) != 0u;
+            }
         } else {
             const uint32_t i = (g - g0) * 64u + lane;
             if (i < n1) slot = fold_in[i];
+            if (slot != kNullEntry) {  // a fold-only path is nothing but pending terms
+                pending = true;
+                sh = in.sh_prim[slot];
+                pr = in.pr_prim[slot];
+            }
         }
         const bool valid = slot != kNullEntry;
+        RecRegs R{};
+        rec_fetch(stage, in, slot & kSlotMask, valid, pending, R);
         ShadeA a{};
-        shade_a<FEAT, kKindNone>(sc, in, slot & kSlotMask, 0u, false, valid && pending, valid, max_depth, a);
+        shade_a<FEAT, kKindNone>(sc, in, R, slot & kSlotMask, 0u, false, sh, pr, pending, valid, max_depth, a);
         if (a.live) film_put(lf, a.orig, a.L);
     }
 }
@@ -1111,44 +1268,39 @@ __global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathS
         if (has_sh) s_job[wave][jsh] = slot | (kRayShadow << 30);
         if (has_pr) s_job[wave][jpr] = slot | (kRayProbe << 30);
         if (has_ex) s_job[wave][jex] = slot | (kRayExt << 30);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        wave_sync_lds();
         const uint32_t n_jobs = nsh + npr + nex;
         n_traced += n_jobs;
         for (uint32_t j = lane; j < n_jobs; j += 64u) {
             const uint32_t job = s_job[wave][j];
             const uint32_t js = job & kSlotMask, kind = job >> 30;
-            const rt_w* jr = rec_words(in, js);
-            const D3 o = ld3w<kWO>(jr);
+            const D3 o = ld3(in.ox, in.oy, in.oz, js);
             double t;
             uint32_t hs = 0;
             int32_t prim;
             if (kind == kRayShadow) {  // Visibility::unoccluded, hittable.rs:25-32
-                const D3 d = ld3w<kWSp>(jr) - o;
+                const D3 d = ld3(in.spx, in.spy, in.spz, js) - o;
                 prim = closest_hit<COUNT>(sc, o + d * kSmall, d, 0.0, kInf, t, ts, &tc);
             } else if (kind == kRayProbe) {
-                prim = closest_hit<COUNT>(sc, o, ld3w<kWPd>(jr), kSmall, kInf, t, ts, &tc);
+                prim = closest_hit<COUNT>(sc, o, ld3(in.pdx, in.pdy, in.pdz, js), kSmall, kInf, t, ts, &tc);
             } else {
-                prim = closest_hit<COUNT>(sc, o, ld3w<kWD>(jr), kSmall, kInf, t, ts, &tc, &hs);
+                prim = closest_hit<COUNT>(sc, o, ld3(in.dx, in.dy, in.dz, js), kSmall, kInf, t, ts, &tc, &hs);
             }
             s_res[wave][j] = make_int2(prim, prim < 0 ? 0 : (int)hit_word(prim, hs));
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        wave_sync_lds();
         if (alive) {
-            int32_t* res = reinterpret_cast<int32_t*>(rec_words(in, slot) + kWRes);
-            if (has_sh) res[0] = s_res[wave][jsh].x;
-            if (has_pr) res[1] = s_res[wave][jpr].x;
-            asm volatile("" ::: "memory");  // shade_a reads these words back through another pointer type
+            const int32_t sh = has_sh ? s_res[wave][jsh].x : -1, pr = has_pr ? s_res[wave][jpr].x : -1;
             int2 hr = make_int2(-1, 0);
             if (has_ex) hr = s_res[wave][jex];
+            RecRegs R{};
+            rec_load(in, slot, true, R);
             ShadeA a{};
-            shade_a<FEAT, kKindAny>(sc, in, slot, (uint32_t)hr.y, hr.x >= 0, true, true, max_depth, a);
-            ShadeOut r{false, false, false, false};
+            shade_a<FEAT, kKindAny>(sc, in, R, slot, (uint32_t)hr.y, hr.x >= 0, sh, pr, true, true, max_depth, a);
+            ShadeRes r{};
             if (a.will_shade) {
                 r = shade_b<FEAT>(sc, out, slot, a);
+                rec_store_direct(out, slot, a, r);
                 n_v++;
             }
             n_r1 += r.emit_ext ? 1u : 0u;

@@ -108,26 +108,32 @@ struct DevScene {
 };
 
 // ----------------------------------------------------------------- path state
-// One RECORD of 256 B per path slot = two 128-B cache lines = four 64-B HBM atoms (round 4; rounds 1-3 kept 34 separate
-// arrays).  A lane's whole state costs the two lines it costs anyway, in WHATEVER order the slots are visited -- which is
-// what lets the shading kernels run on class-pure waves gathered over the whole launch (kernels.hip: the class lists):
-// with separate arrays a gathered wave touched 13-27 lines per load instead of 4.
-// Fields are addressed in 8-byte words (a vec3 is three consecutive words); the fast mode keeps its binary32 values in
-// the low half of each word.  Two such pools ping-pong per bounce (kernels.hip).
-//   line 0, what every bounce reads and rewrites IN FULL (no partly written HBM atom):
-//     w0-2 o   w3-5 d   w6 rng   w7 {orig, flags}   |   w8-10 beta   w11-13 L   w14 {sh_prim, pr_prim}   w15 {hit_prim, hit word}
-//     (w15: k_tail / rt_intersect_batch only; the first atom alone is a camera sample or an extension ray)
-//   line 1, the pending direct-light terms of the previous vertex -- fetched only by paths that carry any:
-//     w16-18 A   w19-21 Q   w22-24 K   w25-27 sp   w28-30 pd   w31 spare
+// What bounds every access pattern on this chip is the number of L2 REQUESTS, not bytes (tools/ubench_partial_write.hip,
+// profiles/r04_ubench_partial_write.txt: 50-75 G requests/s whatever their size up to 128 B; a lane that reads its own
+// 128-B line with eight 16-B loads makes eight requests, eight lanes that read one line together make one).  So:
+//   * what the TRAVERSAL kernel touches -- the rays and their results -- are separate arrays indexed by slot (a wave's
+//     queue entries are mostly consecutive slots: a 64-lane load is 4 requests): o, d, sp, pd; sh_prim, pr_prim;
+//   * what only the SHADING kernels touch is one RECORD of 256 B per slot, two 128-B lines, read and written as WHOLE
+//     LINES by eight lanes each through LDS (kernels.hip: stage_*), in whatever order the class lists name the slots --
+//     which is what lets the shading kernels run on class-pure waves gathered over the whole launch:
+//       line 0 (every bounce): w0-2 o   w3-5 d   w6 rng   w7 {orig, flags}   w8-10 beta   w11-13 L   w14-15 spare
+//       line 1 (only paths with pending direct-light terms): w16-18 A   w19-21 Q   w22-24 K   w25-31 spare
+// Fields are 8-byte words (a vec3 = three consecutive words / array elements); the fast mode keeps its binary32 values
+// in the low half of each.  Two such pools ping-pong per bounce (kernels.hip).
 // o = ray origin (last hit point; spawn_ray adds no offset), d = extension direction, sp = sampled light point (shadow
 // ray target), pd = MIS probe direction, A / Q = pending light-sample / bsdf-sample terms (f * Le * w / pdf), K = beta at
 // the vertex that produced them, orig = film staging slot (sample_local * n_pixels + pixel_local).
 struct PathState {
     char* rec;
+    double *ox, *oy, *oz;     // ray origin (also in the record: the shading kernels read it there)
+    double *dx, *dy, *dz;     // extension direction (likewise)
+    double *spx, *spy, *spz;  // shadow ray target
+    double *pdx, *pdy, *pdz;  // MIS probe direction
+    int32_t* sh_prim;         // closest prim along the shadow ray (Q13)
+    int32_t* pr_prim;         // closest prim along the probe ray
 };
 constexpr uint32_t kRecBytes = 256;
-constexpr int kWO = 0, kWD = 3, kWRng = 6, kWMeta = 7, kWBeta = 8, kWL = 11, kWRes = 14, kWHit = 15, kWA = 16, kWQ = 19, kWK = 22,
-              kWSp = 25, kWPd = 28;
+constexpr int kWO = 0, kWD = 3, kWRng = 6, kWMeta = 7, kWBeta = 8, kWL = 11, kWA = 16, kWQ = 19, kWK = 22;
 // flags
 constexpr uint32_t kBounceMask = 0xffu;
 constexpr uint32_t kSpecular = 1u << 8;
@@ -159,8 +165,9 @@ struct ClsDesc {
     uint8_t variant;  // index into kFeatVariants
     uint8_t kind;     // kKind*
 };
-struct alignas(8) ListEnt {
-    uint32_t slot, hit;
+struct alignas(16) ListEnt {
+    uint32_t slot, hit;  // slot | kEntPending; hit word of the extension ray
+    int32_t sh, pr;      // the shadow / probe ray's result (meaningful with kEntPending)
 };
 struct Lists {
     ListEnt* ent;      // [n_cls][cap]: {slot, hit word}; class c at ent + c * cap

@@ -19,7 +19,9 @@ typedef void (*ShadeLightKernel)(DevScene, PathState, Ctl*, uint32_t, uint32_t, 
 typedef void (*TailKernel)(DevScene, PathState, PathState, Ctl*, uint32_t, uint32_t, const uint32_t*, Lists, double*, DevStats*);
 typedef void (*TraceKernel)(DevScene, PathState, const uint32_t*, Ctl*, uint32_t, DevStats*, TraceTune, MirrorEntry*, uint32_t,
                             const BatchCtl*, unsigned long long, uint32_t*);
-typedef void (*ClassifyKernel)(const uint32_t*, const uint32_t*, Ctl*, uint32_t, Lists);
+typedef void (*ClassifyCountKernel)(const uint32_t*, const uint32_t*, const Ctl*, uint32_t, uint32_t*);
+typedef void (*ClassifyScanKernel)(uint32_t*, uint32_t, Ctl*, uint32_t);
+typedef void (*ClassifyScatterKernel)(const uint32_t*, const uint32_t*, PathState, const Ctl*, uint32_t, const uint32_t*, Lists);
 typedef void (*GenKernel)(PathState, rt_camera, ChunkDesc, const uint32_t*, uint32_t*, const Ctl*);
 typedef void (*PlanKernel)(Ctl*, BatchCtl*, uint32_t, uint32_t, unsigned long long, DevStats*);
 typedef void (*IntersectKernel)(DevScene, const rt_ray*, uint64_t, rt_hit*);
@@ -35,7 +37,9 @@ struct KernelTable {
     GenKernel generate[2];
     IntersectKernel intersect[2];
     PlanKernel plan;
-    ClassifyKernel classify;  // (the same integer code in both precisions: registered twice, one wins)
+    ClassifyCountKernel classify_count;  // (the same integer code in both precisions: registered twice, one wins)
+    ClassifyScanKernel classify_scan;
+    ClassifyScatterKernel classify_scatter;
     ResolveKernel resolve;
     TonemapKernel tonemap;
 };

@@ -20,7 +20,9 @@ struct Reg {
         t.trace[P][2] = K::k_trace<true, false>;
         t.generate[P] = K::k_generate;
         t.intersect[P] = K::k_intersect_batch;
-        t.classify = K::k_classify<0>;
+        t.classify_count = K::k_classify_count<0>;
+        t.classify_scan = K::k_classify_scan<0>;
+        t.classify_scatter = K::k_classify_scatter<0>;
         t.shade_light[P][0] = K::k_shade_light<0>;
         t.shade_light[P][1] = K::k_shade_light<K::kFeatEnv>;
 #if !RT_TU_F32
