@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 3
+#define RT_ABI_VERSION 4  /* 4 (round 4): rt_stats.classify_ms, rt_scene_info.n_classes appended */
 
 /* ---------------------------------------------------------------- status */
 typedef enum rt_status {
@@ -302,8 +302,11 @@ typedef struct rt_stats {
      * time), gather_ms is the host-clock time of the final peer-to-peer film gather.                   */
     double gather_ms;
     uint64_t n_devices;
-    double shade_ms;           /* shading kernel only (HIP events), like trace_ms */
-    uint64_t shade_launches;
+    double shade_ms;           /* shading kernels only (HIP events), like trace_ms: per bounce one kernel
+                                  per vertex class of the scene + the one for escaped / fold-only paths */
+    uint64_t shade_launches;   /* bounces shaded (not kernels)                 */
+    double classify_ms;        /* (ABI 4) the counting sort that deals the traced paths to the lists of
+                                  their vertex classes, between the two (HIP events)                  */
 } rt_stats;
 
 typedef struct rt_ray {
@@ -369,6 +372,8 @@ typedef struct rt_scene_info {
     uint64_t build_from_cache; /* (ABI 3) 1: the host tree was read from the node-local cache
                                   another process published (environment RT_BVH_CACHE=<dir>:
                                   the ranks of one node build a scene's tree once)          */
+    uint64_t n_classes;        /* (ABI 4) vertex classes the scene's primitives fall into (+ 1: escaped):
+                                  shading kernels launched per bounce                                  */
 } rt_scene_info;
 int rt_scene_get_info(const rt_scene* s, rt_scene_info* out);
 

@@ -111,7 +111,7 @@ class rt_stats(C.Structure):
         ("tail_rays", C.c_uint64), ("tail_nodes_fetched", C.c_uint64), ("tail_tris_tested", C.c_uint64),
         ("tail_others_tested", C.c_uint64),
         ("gather_ms", C.c_double), ("n_devices", C.c_uint64),
-        ("shade_ms", C.c_double), ("shade_launches", C.c_uint64),
+        ("shade_ms", C.c_double), ("shade_launches", C.c_uint64), ("classify_ms", C.c_double),
     ]
 
     def as_dict(self):
@@ -135,7 +135,8 @@ class rt_scene_info(C.Structure):
         "n_prims", "n_triangles", "n_others", "n_bvh_nodes", "bvh_depth", "node_bytes", "tri_bytes",
         "other_bytes", "device_bytes_total", "build_flags")] + [("build_ms", C.c_double),
                                                                      ("build_device_ms", C.c_double),
-                                                                     ("build_from_cache", C.c_uint64)]
+                                                                     ("build_from_cache", C.c_uint64),
+                                                                     ("n_classes", C.c_uint64)]
 
 
 # every symbol include/rt_abi.h and include/rt_host.h declare

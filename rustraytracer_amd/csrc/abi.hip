@@ -76,7 +76,7 @@ struct Lane {
     std::vector<hipEvent_t> events;
     size_t ev_i = 0;
     // per-render results of this lane
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_ev, shade_ev;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_ev, classify_ev, shade_ev;
     uint64_t trace_launches = 0, shade_launches = 0;
     int rc = RT_OK;
     char err[512] = "";
@@ -862,6 +862,7 @@ static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cac
     t->info.n_others = np - n_tri;
     t->info.n_bvh_nodes = d.n_nodes;
     t->info.bvh_depth = depth;
+    t->info.n_classes = t->n_cls;
     t->info.node_bytes = sizeof(DevNode);
     // bytes a primitive test requests from its leaf_trav line: the nine coordinates / v[5] + meta, + the index word
     t->info.tri_bytes = 9 * sizeof(double) + sizeof(uint32_t);
@@ -1097,6 +1098,11 @@ static int run_lane(RenderJob& job, int lane_id) {
         hipLaunchKernelGGL(trace_kernel(job.count_trav, job.s->dev.simple_others != 0, job.f32_trace), dim3(tblocks), dim3(256), 0, stream,
                            job.s->dev, ln.st[it & 1], ln.queue[it & 1], ln.ctl, (uint32_t)it, c->stats, c->tune,
                            no_mirror ? nullptr : ln.mirror_d, seq, c->batch, job.batch_total, ln.hitw);
+        if (!no_ev) {
+            LANE_TRY(hipEventRecord(b, stream));
+            ln.trace_ev.emplace_back(a, b);
+        }
+        ln.trace_launches++;
         // the traced paths to the lists of their vertex classes: a counting sort over the queue (count, scan, scatter)
         {
             const uint32_t cblocks = std::min((3u * bound_active + 255u) / 256u + 1u, std::min((uint32_t)c->num_cus * 8u, 8192u / 4u));
@@ -1106,19 +1112,25 @@ static int run_lane(RenderJob& job, int lane_id) {
             hipLaunchKernelGGL(rtk::kernel_table().classify_scatter, dim3(cblocks), dim3(256), 0, stream, ln.queue[it & 1], ln.hitw, ln.st[it & 1],
                                ln.ctl, (uint32_t)it, ln.cls_tab, ln.lists);
         }
-        if (!no_ev) {
-            LANE_TRY(hipEventRecord(b, stream));
-            ln.trace_ev.emplace_back(a, b);
+        hipEvent_t b2 = b;
+        if (!no_ev) {  // (the classify launches run from event b, the end of k_trace, to this one)
+            b2 = get_event(ln.events, ln.ev_i++);
+            if (!b2) {
+                job.abort.store(true);
+                return lane_fail(ln, RT_ERR_HIP, "hipEventCreate failed");
+            }
+            LANE_TRY(hipEventRecord(b2, stream));
+            ln.classify_ev.emplace_back(b, b2);
         }
-        ln.trace_launches++;
         // one kernel per vertex class, the heaviest instances first; then the paths that end without a vertex (escaped,
         // fold only).  Persistent grids: a class with few paths this bounce costs a launch, not a grid of empty blocks.
+        const CamArgs cam_args{job.cam, job.batch, c->pix_list};  // (a camera sample's first vertex: scene_dev.h, kEntFresh)
         for (uint32_t k = 1; k < job.s->n_cls; k++)
             hipLaunchKernelGGL(shade_cls_kernel(job.s->cls[k], job.f32_shade), dim3(std::min(shade_want, (uint32_t)job.shade_blocks[k])), dim3(256), 0,
                                stream, job.s->dev, ln.st[it & 1], ln.st[(it + 1) & 1], ln.ctl, (uint32_t)it, cfg->max_depth, ln.lists, k,
-                               ln.queue[(it + 1) & 1], ln.q_cap, ln.slot_cap, c->lf, c->stats);
+                               ln.queue[(it + 1) & 1], ln.q_cap, ln.slot_cap, c->lf, c->stats, cam_args);
         hipLaunchKernelGGL(shade_light_kernel(job.s->dev.env.light >= 0, job.f32_shade), dim3(std::min(shade_want, (uint32_t)job.shade_blocks[0])), dim3(256),
-                           0, stream, job.s->dev, ln.st[it & 1], ln.ctl, (uint32_t)it, cfg->max_depth, ln.lists, c->lf);
+                           0, stream, job.s->dev, ln.st[it & 1], ln.ctl, (uint32_t)it, cfg->max_depth, ln.lists, c->lf, cam_args);
         if (!no_ev) {  // the shading kernel runs from event b (end of k_trace) to this one
             hipEvent_t e = get_event(ln.events, ln.ev_i++);
             if (!e) {
@@ -1126,7 +1138,7 @@ static int run_lane(RenderJob& job, int lane_id) {
                 return lane_fail(ln, RT_ERR_HIP, "hipEventCreate failed");
             }
             LANE_TRY(hipEventRecord(e, stream));
-            ln.shade_ev.emplace_back(b, e);
+            ln.shade_ev.emplace_back(b2, e);
         }
         ln.shade_launches++;
     }
@@ -1201,7 +1213,7 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
         // (pix is a local: the copy has to finish before it goes out of scope on the early-return paths)
         HIP_TRY(hipMemcpyAsync(c->pix_list, c->last_pix.data(), NP * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     }
-    double kernel_ms = 0.0, trace_ms = 0.0, shade_ms = 0.0;
+    double kernel_ms = 0.0, trace_ms = 0.0, shade_ms = 0.0, classify_ms = 0.0;
     uint64_t trace_launches = 0, shade_launches = 0;
     if (NP > 0 && pass_spp > 0) {
         // batch shape: PB pixels x ns samples, at most kBatchMax camera samples (film staging size)
@@ -1289,6 +1301,7 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
             Lane& ln = c->lanes[i];
             ln.ev_i = 0;
             ln.trace_ev.clear();
+            ln.classify_ev.clear();
             ln.shade_ev.clear();
             ln.trace_launches = 0;
             ln.shade_launches = 0;
@@ -1351,6 +1364,10 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
                 HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
                 shade_ms += ms;
             }
+            for (auto& pr : ln.classify_ev) {
+                HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+                classify_ms += ms;
+            }
             trace_launches += ln.trace_launches;
             shade_launches += ln.shade_launches;
         }
@@ -1384,6 +1401,7 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
         stats->n_devices = 1;
         stats->shade_ms = shade_ms;
         stats->shade_launches = shade_launches;
+        stats->classify_ms = classify_ms;
         if (getenv("RT_DIAG")) {
             unsigned long long d[4] = {0, 0, 0, 0}, over64 = 0, over256 = 0;
             for (int i = 0; i < kStatShards; i++) {
@@ -1545,7 +1563,7 @@ static int render_multi(rt_context* c, rt_scene* s, const rt_camera* cam, const 
             t.nodes_fetched += st[i].nodes_fetched; t.tris_tested += st[i].tris_tested;
             t.others_tested += st[i].others_tested; t.trace_ms += st[i].trace_ms;
             t.trace_launches += st[i].trace_launches; t.tail_rays += st[i].tail_rays;
-            t.shade_ms += st[i].shade_ms; t.shade_launches += st[i].shade_launches;
+            t.shade_ms += st[i].shade_ms; t.shade_launches += st[i].shade_launches; t.classify_ms += st[i].classify_ms;
             t.tail_nodes_fetched += st[i].tail_nodes_fetched; t.tail_tris_tested += st[i].tail_tris_tested;
             t.tail_others_tested += st[i].tail_others_tested;
             t.kernel_ms = std::max(t.kernel_ms, st[i].kernel_ms);  // the devices run side by side

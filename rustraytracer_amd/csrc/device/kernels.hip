@@ -249,6 +249,41 @@ RTD void cursor_pad(const Cursor& c, uint32_t* arr, uint32_t cap) {
 // statistics go to kStatShards cache lines that the host sums
 RTD DevStats* stat_shard(DevStats* stats) { return stats + (blockIdx.x & (kStatShards - 1)); }
 
+// One camera sample of the batch: integrator.rs:357-366 + sampler.rs:606-613 + geometry.rs:177-190 (+ util.rs:105-113).
+// g = its index in the batch = its film staging slot.  Run by k_generate (the ray) and again by the kernel that shades
+// the sample's first vertex (ray, RNG state), which is cheaper than carrying a 128-B record line from one to the other.
+RTD void camera_sample(const rt_camera& cam, const ChunkDesc& ck, const uint32_t* __restrict__ pix_list, uint32_t g, D3& o, D3& d,
+                       uint64_t& rng_out) {
+    const uint32_t s_local = g / ck.n_pixels, p_local = g - s_local * ck.n_pixels;
+    const uint32_t pix = pix_list[ck.pixel_base + p_local];
+    const uint32_t px = pix % ck.width, py = pix / ck.width;
+    uint64_t rng = rng_init(ck.seed, (uint64_t)pix, (uint64_t)(ck.sample_base + s_local));
+    const double ox = rng_next(rng), oy = rng_next(rng);
+    (void)rng_next(rng);  // time
+    (void)rng_next(rng);  // lens.x
+    (void)rng_next(rng);  // lens.y
+    const double fx = (double)px + ox, fy = (double)py + oy;
+    const double u = fx / (double)ck.width, v = fy / (double)ck.height;
+    double dx, dy;
+    for (;;) {  // rand_in_disk
+        dx = rng_next(rng);
+        dy = rng_next(rng);
+        if (dx * dx + dy * dy < 1.0) break;
+    }
+    const D3 in_disk = d3(dx, dy, 0.0) * cam.lens_radius;
+    const D3 cu = d3(cam.u[0], cam.u[1], cam.u[2]), cv = d3(cam.v[0], cam.v[1], cam.v[2]);
+    const D3 offset = cu * in_disk.x + cv * in_disk.y;
+    const D3 origin = d3(cam.origin[0], cam.origin[1], cam.origin[2]);
+    const D3 ulc = d3(cam.upper_left_corner[0], cam.upper_left_corner[1], cam.upper_left_corner[2]);
+    const D3 ho = d3(cam.horizontal_offset[0], cam.horizontal_offset[1], cam.horizontal_offset[2]);
+    const D3 vo = d3(cam.vertical_offset[0], cam.vertical_offset[1], cam.vertical_offset[2]);
+    const D3 to = ulc + ho * u - vo * v;
+    const D3 dir = to - origin;
+    (void)rng_next(rng);  // rand_range(t0, t1)
+    o = origin + offset;
+    d = dir - offset;
+    rng_out = rng;
+}
 // ------------------------------------------------------------------ generate
 // (RT_KERNELS_CORE: the kernels that are not templates are compiled by ONE translation unit per precision, tu/tu_core.hip)
 #if defined(RT_KERNELS_CORE) && !defined(RT_F32)  // (precision-independent: compiled once, in the f64 namespace)
@@ -290,54 +325,20 @@ __global__ void k_plan(Ctl* ctl, BatchCtl* batch, uint32_t it, uint32_t pool, un
 #endif
 
 #ifdef RT_KERNELS_CORE
-// integrator.rs:357-366 + sampler.rs:606-613 + geometry.rs:177-190 (+ util.rs:105-113)
+// the batch's next camera samples: their rays, where the traversal kernel reads them, and their queue entries
 __global__ __launch_bounds__(256) void k_generate(PathState st, rt_camera cam, ChunkDesc ck,
                                                   const uint32_t* __restrict__ pix_list, uint32_t* queue,
                                                   const Ctl* ctl) {
-    __shared__ rt_w2 s_stage[4][kStageWave];
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t n_gen = ctl->gen_count;
-    if (blockIdx.x * blockDim.x >= n_gen) return;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t wave_first = idx - lane;  // wave-uniform
-    const bool valid = idx < n_gen;
+    if (idx >= ctl->gen_count) return;
     const uint32_t g = ctl->gen_first + idx;  // path index inside the batch = film staging slot
     const uint32_t slot = ctl->gen_slot + idx;
-    if (valid) {
-        const uint32_t s_local = g / ck.n_pixels, p_local = g - s_local * ck.n_pixels;
-        const uint32_t pix = pix_list[ck.pixel_base + p_local];
-        const uint32_t px = pix % ck.width, py = pix / ck.width;
-        uint64_t rng = rng_init(ck.seed, (uint64_t)pix, (uint64_t)(ck.sample_base + s_local));
-        const double ox = rng_next(rng), oy = rng_next(rng);
-        (void)rng_next(rng);  // time
-        (void)rng_next(rng);  // lens.x
-        (void)rng_next(rng);  // lens.y
-        const double fx = (double)px + ox, fy = (double)py + oy;
-        const double u = fx / (double)ck.width, v = fy / (double)ck.height;
-        double dx, dy;
-        for (;;) {  // rand_in_disk
-            dx = rng_next(rng);
-            dy = rng_next(rng);
-            if (dx * dx + dy * dy < 1.0) break;
-        }
-        const D3 in_disk = d3(dx, dy, 0.0) * cam.lens_radius;
-        const D3 cu = d3(cam.u[0], cam.u[1], cam.u[2]), cv = d3(cam.v[0], cam.v[1], cam.v[2]);
-        const D3 offset = cu * in_disk.x + cv * in_disk.y;
-        const D3 origin = d3(cam.origin[0], cam.origin[1], cam.origin[2]);
-        const D3 ulc = d3(cam.upper_left_corner[0], cam.upper_left_corner[1], cam.upper_left_corner[2]);
-        const D3 ho = d3(cam.horizontal_offset[0], cam.horizontal_offset[1], cam.horizontal_offset[2]);
-        const D3 vo = d3(cam.vertical_offset[0], cam.vertical_offset[1], cam.vertical_offset[2]);
-        const D3 to = ulc + ho * u - vo * v;
-        const D3 dir = to - origin;
-        (void)rng_next(rng);  // rand_range(t0, t1)
-        // line 0 of the record in full: o, d, rng, {orig, flags}, beta = 1, L = 0 (whole-line stores, see stage_line)
-        stage_line0(s_stage[wave], lane, slot, origin + offset, dir - offset, rng, g, 0u, white(), black());
-        st3(st.ox, st.oy, st.oz, slot, origin + offset);  // (the ray itself, where the traversal kernel reads it)
-        st3(st.dx, st.dy, st.dz, slot, dir - offset);
-        queue[ctl->gen_q + idx] = slot | (kRayExt << 30);
-    }
-    const uint32_t left = wave_first < n_gen ? n_gen - wave_first : 0u;
-    stage_flush(s_stage[wave], st, left < 64u ? left : 64u, 0u);
+    D3 o, d;
+    uint64_t rng;
+    camera_sample(cam, ck, pix_list, g, o, d, rng);
+    st3(st.ox, st.oy, st.oz, slot, o);
+    st3(st.dx, st.dy, st.dz, slot, d);
+    queue[ctl->gen_q + idx] = slot | (kRayExt << 30);
 }
 #endif  // RT_KERNELS_CORE
 
@@ -696,6 +697,8 @@ __global__ __launch_bounds__(256) void k_classify_scatter(const uint32_t* __rest
     uint32_t at[kMaxCls];
 #pragma unroll
     for (int c = 0; c < kMaxCls; c++) at[c] = (uint32_t)c < lists.n_cls ? offsets[(uint32_t)c * n_waves + wave_g] : 0u;
+    // the camera samples k_generate appended to this queue: entries [gen_q, gen_q + gen_count), sample gen_first + k
+    const uint32_t fresh_lo = ctl->gen_q, fresh_n = ctl->gen_count, fresh_g = ctl->gen_first;
     const unsigned long long below = (1ull << lane) - 1ull;
     // four groups per round: their loads are in flight together
     for (uint32_t g0 = g_first; g0 < g_end; g0 += 4u) {
@@ -719,13 +722,16 @@ __global__ __launch_bounds__(256) void k_classify_scatter(const uint32_t* __rest
             const uint32_t e = e4[u], hw = hw4[u];
             const bool ext = (e >> 30) == kRayExt;
             const uint32_t cls = ext ? (hw >> kClsShift & (uint32_t)(kMaxCls - 1)) : (uint32_t)kMaxCls;
-            const uint32_t slot_word = (e & kSlotMask) | ((e & kQPending) ? kEntPending : 0u);
+            const uint32_t qi = (g0 + u) * 64u + lane;
+            const bool fresh = qi - fresh_lo < fresh_n;  // (unsigned: also false below fresh_lo)
+            const uint32_t slot_word = (e & kSlotMask) | ((e & kQPending) ? kEntPending : 0u) | (fresh ? kEntFresh : 0u);
+            const int32_t w2 = fresh ? (int32_t)(fresh_g + (qi - fresh_lo)) : sh4[u];
 #pragma unroll
             for (int c = 0; c < kMaxCls; c++) {
                 const bool mine = cls == (uint32_t)c;
                 const unsigned long long m = __ballot(mine);
                 const uint32_t to = at[c] + (uint32_t)__popcll(m & below);
-                if (mine && to < lists.cap) lists.ent[(size_t)c * lists.cap + to] = ListEnt{slot_word, hw, sh4[u], pr4[u]};
+                if (mine && to < lists.cap) lists.ent[(size_t)c * lists.cap + to] = ListEnt{slot_word, hw, w2, pr4[u]};
                 at[c] += (uint32_t)__popcll(m);
             }
         }
@@ -757,11 +763,29 @@ struct ShadeA {
 RTD bool rec_wants_line1(const RecRegs& R, bool valid, bool pending) {
     return valid && pending && ((uint32_t)(R.p[3].y >> 32) & (kHasShadow | kHasProbe)) != 0u;
 }
-RTD void rec_fetch(rt_w2* stage, const PathState& in, uint32_t slot, bool valid, bool pending, RecRegs& R) {
+// line 0 of a camera sample that has not been shaded yet (scene_dev.h: kEntFresh): beta = 1, L = 0, no flags
+RTD void rec_fresh(const CamArgs& ca, uint32_t g, RecRegs& R) {
+    D3 o, d;
+    uint64_t rng;
+    camera_sample(ca.cam, ca.ck, ca.pix_list, g, o, d, rng);
+    R.p[0].x = r2w(o.x); R.p[0].y = r2w(o.y);
+    R.p[1].x = r2w(o.z); R.p[1].y = r2w(d.x);
+    R.p[2].x = r2w(d.y); R.p[2].y = r2w(d.z);
+    R.p[3].x = rng; R.p[3].y = (rt_w)g;
+    R.p[4].x = r2w(1.0); R.p[4].y = r2w(1.0);
+    R.p[5].x = r2w(1.0); R.p[5].y = r2w(0.0);
+    R.p[6].x = r2w(0.0); R.p[6].y = r2w(0.0);
+}
+RTD void rec_fetch(rt_w2* stage, const PathState& in, uint32_t slot, bool valid, bool pending, bool fresh, uint32_t fresh_g, const CamArgs& ca,
+                   RecRegs& R) {
     const uint32_t lane = threadIdx.x & 63u;
-    stage_fetch(stage, in, valid ? slot : kNullEntry, 0u);
+    const bool stored = valid && !fresh;
+    if (__ballot(stored)) {
+        stage_fetch(stage, in, stored ? slot : kNullEntry, 0u);
 #pragma unroll
-    for (int k = 0; k < 7; k++) R.p[k] = stage[lane * kStagePitch + k];
+        for (int k = 0; k < 7; k++) R.p[k] = stage[lane * kStagePitch + k];
+    }
+    if (valid && fresh) rec_fresh(ca, fresh_g, R);
     const bool fold = rec_wants_line1(R, valid, pending);
     if (__ballot(fold)) {
         wave_sync_lds();  // (every lane has read its line 0)
@@ -1045,7 +1069,7 @@ RTD void rec_store_direct(const PathState& out, uint32_t os, const ShadeA& a, co
 template <int FEAT, int KIND>
 __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade_cls(DevScene sc, PathState in, PathState out, Ctl* ctl, uint32_t it_abs,
                                                uint32_t max_depth, Lists lists, uint32_t cls, uint32_t* queue_out, uint32_t q_cap,
-                                               uint32_t slot_cap, f64_t* lf, DevStats* stats) {
+                                               uint32_t slot_cap, f64_t* lf, DevStats* stats, CamArgs ca) {
     const uint32_t itn = (it_abs + 1) % kRing;
     const uint32_t n = ctl->cls_count[it_abs & 3u][cls][0];
     const uint32_t n_groups = (n + 63u) / 64u;
@@ -1073,9 +1097,9 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade_cls(DevScen
         if (i < n) e = ent[i];
         const bool valid = e.slot != kNullEntry;
         // ---- records in
-        const bool pending = valid && (e.slot & kEntPending);
+        const bool pending = valid && (e.slot & kEntPending), fresh = valid && (e.slot & kEntFresh);
         RecRegs R{};
-        rec_fetch(stage, in, e.slot & kSlotMask, valid, pending, R);
+        rec_fetch(stage, in, e.slot & kSlotMask, valid, pending, fresh, (uint32_t)e.sh, ca, R);
         // ---- compute
         ShadeA a{};
         shade_a<FEAT, KIND>(sc, in, R, e.slot & kSlotMask, e.hit, true, e.sh, e.pr, pending, valid, max_depth, a);
@@ -1149,7 +1173,7 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade_cls(DevScen
 // of the environment, film staging -- a few dozen registers, one whole line of the record for most of them.
 template <int FEAT>
 __global__ __launch_bounds__(256, 4) void k_shade_light(DevScene sc, PathState in, Ctl* ctl, uint32_t it_abs, uint32_t max_depth,
-                                                     Lists lists, f64_t* lf) {
+                                                     Lists lists, f64_t* lf, CamArgs ca) {
     const uint32_t n0 = ctl->cls_count[it_abs & 3u][0][0], n1 = ctl->fold_count[it_abs & 3u][0];
     const uint32_t g0 = (n0 + 63u) / 64u, n_groups = g0 + (n1 + 63u) / 64u;
     const uint32_t lane = threadIdx.x & 63u, n_waves = gridDim.x * (blockDim.x >> 6);
@@ -1159,7 +1183,7 @@ __global__ __launch_bounds__(256, 4) void k_shade_light(DevScene sc, PathState i
     for (uint32_t g = blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); g < n_groups; g += n_waves) {
         uint32_t slot = kNullEntry;
         int32_t sh = -1, pr = -1;
-        bool pending = false;
+        bool pending = false, fresh = false;
         if (g < g0) {
             const uint32_t i = g * 64u + lane;
             if (i < n0) {
@@ -1168,6 +1192,7 @@ __global__ __launch_bounds__(256, 4) void k_shade_light(DevScene sc, PathState i
                 sh = e.sh;
                 pr = e.pr;
                 pending = slot != kNullEntry && (slot & kEntPending) != 0u;
+                fresh = slot != kNullEntry && (slot & kEntFresh) != 0u;
             }
         } else {
             const uint32_t i = (g - g0) * 64u + lane;
@@ -1180,7 +1205,7 @@ __global__ __launch_bounds__(256, 4) void k_shade_light(DevScene sc, PathState i
         }
         const bool valid = slot != kNullEntry;
         RecRegs R{};
-        rec_fetch(stage, in, slot & kSlotMask, valid, pending, R);
+        rec_fetch(stage, in, slot & kSlotMask, valid, pending, fresh, (uint32_t)sh, ca, R);
         ShadeA a{};
         shade_a<FEAT, kKindNone>(sc, in, R, slot & kSlotMask, 0u, false, sh, pr, pending, valid, max_depth, a);
         if (a.live) film_put(lf, a.orig, a.L);

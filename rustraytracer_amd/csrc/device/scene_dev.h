@@ -149,6 +149,10 @@ constexpr uint32_t kRayExt = 0u, kRayShadow = 1u, kRayProbe = 2u, kRayNone = 3u;
 constexpr uint32_t kSlotMask = 0x1fffffffu, kQPending = 1u << 29;
 constexpr uint32_t kNullEntry = 0xffffffffu;  // unused queue / list entry
 constexpr uint32_t kEntPending = 1u << 30;    // in ListEnt::slot
+// A camera sample has no record until its first vertex is shaded: everything in it follows from its index in the batch
+// (kernels.hip: camera_sample), which k_classify hands on in ListEnt::sh.  k_generate writes the ray only -- 52 B per
+// sample instead of 180, and the shading kernels do not fetch 128 B that say "beta = 1, L = 0".
+constexpr uint32_t kEntFresh = 1u << 29;
 
 // ---- vertex classes (round 4).  Every primitive belongs to a class = (smallest shading-kernel instance that covers its
 // material, kind of hit record: mesh slot / sphere-rect / generic); class 0 = the extension ray escaped.  A leaf's class
@@ -218,6 +222,13 @@ struct ChunkDesc {
     uint32_t sample_base;  // first sample index
     uint32_t width, height;
     uint64_t seed;
+};
+
+// what a shading kernel needs to run a camera sample again (kernels.hip: camera_sample, scene_dev.h: kEntFresh)
+struct CamArgs {
+    rt_camera cam;
+    ChunkDesc ck;
+    const uint32_t* pix_list;
 };
 
 struct TraceTune {
