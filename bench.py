@@ -16,11 +16,13 @@ pixels are packed and gathered to rank 0 over RCCL/xGMI (rustraytracer_amd/dist.
 time is reported separately (`gather_ms_per_step`) and is inside the timed region.
 
 One JSON line on rank 0 with
-  roofline      dominant kernel k_trace: algorithmic bytes (device traversal counters of the same kernel and
-                BVH, the fused tail launch's share subtracted) over HIP-event launch time; `traffic` = HBM bytes
-                per launch from the rocprofv3 PMC passes committed under profiles/ (null if none for this
-                workload), `hbm_frac_rocprof` the measured-HBM fraction beside the algorithmic `frac`;
-                `kernels.k_shade` = the same accounting for the shading kernel
+  roofline      per kernel group (k_trace / k_shade = the class kernels + the light kernel / k_classify): share of the
+                device time (HIP events), algorithmic bytes per step over that time, and -- from the rocprofv3 PMC
+                passes committed under profiles/, when they belong to the library running now -- the measured HBM
+                fractions (all bytes, reads only).  The top level names the group with the LARGEST share of device
+                time (`kernel`); `frac` is its measured fraction when the profile is current, else the algorithmic one;
+                an algorithmic fraction above 1 (cache hits counted) is never reported as `frac`
+  rays          R1 / R2 / R3 of SURVEY.md 8(d) (extension incl. primary, shadow, MIS probe)
   cpu_baseline  the oracle in reference-shaped mode on the host cores, bounded sample (rank 0, N = 1 only)
   extra         (N = 1) the smaller single-GPU configs C2 and C3 measured the same way, for continuity with
                 round 1's numbers
@@ -61,10 +63,42 @@ WORKLOADS = {
     "tiny": ("cornell_box_statue", dict(mesh_faces=20000, variant=0), 128, 128, 8, "tiny smoke workload"),
 }
 
-# algorithmic bytes per shaded vertex of k_shade (f64 parity layout): 244 B path state read
-# + 244 B written + the winner's scene records (72 B vertices + 72 B normals + 8 B meta + 120 B primitive or
-# material record, SURVEY.md 8d's B_shade doubled for f64 = 272 B)
-SHADE_BYTES_PER_VERTEX = 244 + 244 + 272
+# Algorithmic bytes of the shading kernels (round-4 layout):
+#   per path entering a bounce (= extension ray, R1): its 16-B list entry; line 0 of its record (128 B) unless it is a
+#     camera sample, which has no record yet;
+#   per shaded vertex: line 0 of the survivor's record written (128 B), its ray written to the ray arrays (48 B), the
+#     winner's scene records (72 B vertices + 72 B normals + 8 B meta + 120 B primitive or material record: SURVEY.md
+#     8d's B_shade doubled for f64 = 272 B);
+#   per vertex with pending direct-light terms (counted as max(R2, R3)): line 1 written and read back (2 x 128 B) and the
+#     shadow target / probe direction (24 B per ray).
+SHADE_BYTES_PER_VERTEX = 128 + 48 + 272
+CLASSIFY_BYTES_PER_RAY = 2 * 8 + 16  # queue entry + hit word read by the count and by the scatter pass, one 16-B list entry
+
+
+def shade_bytes(st):
+    pending = max(st.rays_shadow, st.rays_probe)
+    return (16 * st.rays_extension + 128 * max(st.rays_extension - st.paths, 0) + SHADE_BYTES_PER_VERTEX * st.vertices_shaded +
+            256 * pending + 24 * (st.rays_shadow + st.rays_probe))
+
+
+def pick_roofline(kernels):
+    """The top level of the `roofline` object from its per-kernel entries (pure: tests/test_host_cpu.py checks it).
+    kernel = the entry with the largest share of device time.  frac = its measured HBM fraction when there is one
+    (hbm_frac_rocprof), else its algorithmic fraction -- unless that exceeds 1 (requested bytes incl. cache hits cannot
+    be a fraction of the HBM peak), in which case frac is null and the number is kept as frac_algorithmic_incl_cache_hits."""
+    name = max(kernels, key=lambda k: kernels[k].get("share_of_device_time") or 0.0)
+    k = kernels[name]
+    alg = k.get("frac_algorithmic")
+    meas = k.get("hbm_frac_rocprof")
+    out = {"kernel": name, "achieved": k.get("achieved"), "share_of_device_time": k.get("share_of_device_time"),
+           "frac_algorithmic_incl_cache_hits": alg, "hbm_frac_rocprof": meas, "hbm_read_frac_rocprof": k.get("hbm_read_frac_rocprof")}
+    if meas is not None:
+        out["frac"], out["frac_is"] = meas, "measured (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE of this kernel group / its time / peak)"
+    elif alg is not None and alg <= 1.0:
+        out["frac"], out["frac_is"] = alg, "algorithmic (no current counter profile)"
+    else:
+        out["frac"], out["frac_is"] = None, "withheld: no current counter profile and the algorithmic fraction exceeds 1"
+    return out
 
 
 def trace_bytes(st, info):
@@ -220,6 +254,18 @@ class Bench:
             self.ctx.close()
 
 
+def fnv1a_film(d_rgb, d_n):
+    """The device film as one number: FNV-1a (64 bit) over the SHA-256 digests of its 1-MiB blocks (sums as f64, then
+    counts as i32) -- byte-by-byte FNV over 70 MB is too slow in Python."""
+    import hashlib
+    h = 0xcbf29ce484222325
+    data = d_rgb.cpu().numpy().tobytes() + d_n.cpu().numpy().tobytes()
+    for off in range(0, len(data), 1 << 20):
+        for byte in hashlib.sha256(data[off:off + (1 << 20)]).digest():
+            h = ((h ^ byte) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    return "%016x" % h
+
+
 def timed(b, steps, warmup, barrier):
     if warmup == 0 and b.world > 1:
         # one-off set-up that is not the measured work: RCCL connects peers at the first gather (1 spp of the same
@@ -234,7 +280,7 @@ def timed(b, steps, warmup, barrier):
     barrier()
     b.gather_s = 0.0
     acc = {"rays": 0, "trace_ms": 0.0, "kernel_ms": 0.0, "launches": 0, "shade_ms": 0.0, "shade_launches": 0,
-           "vertices": 0}
+           "vertices": 0, "classify_ms": 0.0, "r1": 0, "r2": 0, "r3": 0}
     t0 = time.perf_counter()
     for _ in range(steps):
         st = b.step()
@@ -244,23 +290,57 @@ def timed(b, steps, warmup, barrier):
         acc["launches"] += st.trace_launches
         acc["shade_ms"] += st.shade_ms
         acc["shade_launches"] += st.shade_launches
+        acc["classify_ms"] += st.classify_ms
+        acc["r1"] += st.rays_extension
+        acc["r2"] += st.rays_shadow
+        acc["r3"] += st.rays_probe
         acc["vertices"] += st.vertices_shaded
     barrier()
     acc["dt"] = time.perf_counter() - t0
     return acc
 
 
+def pmc_groups(rec):
+    """Per kernel group, the HBM bytes per step of a committed counter profile (profiles/trace_pmc_<workload>.json:
+    per_kernel_hbm_read_bytes_per_step / ..write..): k_trace = the timed instance, k_shade = class kernels + light
+    kernel, k_classify = the three launches of the counting sort."""
+    rd, wr = rec.get("per_kernel_hbm_read_bytes_per_step") or {}, rec.get("per_kernel_hbm_write_bytes_per_step") or {}
+    out = {}
+    for grp, needles in (("k_trace", ("k_trace<false",)), ("k_shade", ("k_shade_cls", "k_shade_light")), ("k_classify", ("k_classify_",))):
+        r = sum(v for k, v in rd.items() if any(n in k for n in needles))
+        w = sum(v for k, v in wr.items() if any(n in k for n in needles))
+        if r or w:
+            out[grp] = (r, w)
+    return out
+
+
 def roofline(b, acc, stc, steps):
-    """k_trace (dominant) and k_shade: algorithmic bytes per launch over mean HIP-event launch duration."""
+    """Per kernel group: algorithmic bytes per step over its HIP-event time, and the measured HBM fractions of the
+    committed counter profile when it was taken from the library that is running; top level: pick_roofline()."""
+    steps = max(steps, 1)
     alg, trace_rays = trace_bytes(stc, b.info)  # per render, this rank
-    launches_per_step = acc["launches"] / max(steps, 1)
+    launches_per_step = acc["launches"] / steps
     avg_launch_s = (acc["trace_ms"] / 1e3) / max(acc["launches"], 1)
-    bytes_per_launch = alg / max(launches_per_step, 1)
-    achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+    dev_ms = max(acc["kernel_ms"], 1e-9)
+    groups = {
+        "k_trace": {"ms_per_step": acc["trace_ms"] / steps, "algorithmic_bytes_per_step": alg},
+        "k_shade": {"ms_per_step": acc["shade_ms"] / steps, "algorithmic_bytes_per_step": shade_bytes(stc),
+                    "kernels_per_bounce": b.info.get("n_classes"),
+                    "note": "one kernel per vertex class of the scene + one for escaped / fold-only paths; f64 VALU issue "
+                            "and latency share the bound with bytes (DESIGN.md section 4)"},
+        "k_classify": {"ms_per_step": acc["classify_ms"] / steps, "algorithmic_bytes_per_step": CLASSIFY_BYTES_PER_RAY * stc.rays},
+    }
+    for g in groups.values():
+        s = g["ms_per_step"] / 1e3
+        g["bound"], g["peak"], g["unit"] = "hbm", HBM_PEAK_GBS, "GB/s"
+        g["achieved"] = g["algorithmic_bytes_per_step"] / s / 1e9 if s > 0 else 0.0
+        g["frac_algorithmic"] = g["achieved"] / HBM_PEAK_GBS
+        g["share_of_device_time"] = g["ms_per_step"] * steps / dev_ms
+        g["hbm_frac_rocprof"] = g["hbm_read_frac_rocprof"] = g["traffic_per_step"] = None
     # Counter figures come from a committed rocprofv3 --pmc profile (counters cannot be read inside this run); the
-    # profile names the kernel build it was taken from, and the figure is WITHHELD (null, with the reason in
-    # traffic_source.stale) when the k_trace machine code of the library running now hashes differently.
-    traffic = traffic_step = frac_pmc = frac_step = None
+    # profile names the kernel build it was taken from, and the figures are WITHHELD (null, with the reason in
+    # traffic_source.stale) when the machine code of the library running now hashes differently.
+    traffic = frac_step = None
     source = None
     pmc = os.path.join(ROOT, "profiles", f"trace_pmc_{b.name}.json")
     if b.world == 1 and b.precision == 0 and os.path.exists(pmc):
@@ -268,15 +348,12 @@ def roofline(b, acc, stc, steps):
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             from kernel_hash import kernel_hash
             rec = json.load(open(pmc))
-            now = kernel_hash("k_trace")
-            prof_hash = (rec.get("kernel_object_hash") or {}).get("sha256")
-            source = {"file": os.path.relpath(pmc, ROOT), "commit": rec.get("commit"),
-                      "kernel_object_hash": prof_hash, "running_kernel_object_hash": now and now["sha256"],
-                      "stale": None}
-            if prof_hash is None:
-                source["stale"] = "the profile predates kernel hashing (round 2): figure kept, build unverified"
-            elif now is None or now["sha256"] != prof_hash:
-                source["stale"] = "k_trace was rebuilt since the profile was taken: counter figures withheld"
+            now = kernel_hash("k_")
+            prof_hash = rec.get("library_kernels_hash") and rec["library_kernels_hash"].get("sha256")
+            source = {"file": os.path.relpath(pmc, ROOT), "commit": rec.get("commit"), "library_kernels_hash": prof_hash,
+                      "running_library_kernels_hash": now and now["sha256"], "stale": None}
+            if prof_hash is None or now is None or now["sha256"] != prof_hash:
+                source["stale"] = "the kernels were rebuilt since the profile was taken: counter figures withheld"
             else:
                 # bytes per LAUNCH only carry over when a step is cut into the same launches (pool size, batch size)
                 prof_lps = float(rec.get("launches") or 0) / max(float(rec.get("steps_profiled") or 1), 1.0)
@@ -284,41 +361,37 @@ def roofline(b, acc, stc, steps):
                 if prof_lps and abs(prof_lps - launches_per_step) > 0.05 * prof_lps:
                     source["stale"] = ("the profile was taken with %.0f k_trace launches per step, this run has %.0f "
                                        "(pool / batch size): counter figures withheld" % (prof_lps, launches_per_step))
-            if source["stale"] is None or prof_hash is None:
-                traffic = float(rec.get("hbm_bytes_per_launch"))
-                traffic_step = traffic * launches_per_step
-                frac_pmc = traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS
-                # all kernels of a step (trace + shade + generate + resolve + tail): HBM bytes per step / ms_per_step
+            if source["stale"] is None:
+                for name, (r, w) in pmc_groups(rec).items():
+                    s = groups[name]["ms_per_step"] / 1e3
+                    if s > 0:
+                        groups[name]["traffic_per_step"] = r + w
+                        groups[name]["hbm_frac_rocprof"] = (r + w) / s / 1e9 / HBM_PEAK_GBS
+                        groups[name]["hbm_read_frac_rocprof"] = r / s / 1e9 / HBM_PEAK_GBS
+                if groups["k_trace"]["traffic_per_step"]:
+                    traffic = groups["k_trace"]["traffic_per_step"] / max(launches_per_step, 1)
                 all_k = rec.get("hbm_bytes_per_step_all_kernels")
-                whole_lib_same = rec.get("library_kernels_hash") == kernel_hash("k_")
-                if all_k and whole_lib_same:
-                    frac_step = float(all_k) / (acc["dt"] / max(steps, 1)) / 1e9 / HBM_PEAK_GBS
+                if all_k:  # all kernels of a step: HBM bytes per step / ms_per_step
+                    frac_step = float(all_k) / (acc["dt"] / steps) / 1e9 / HBM_PEAK_GBS
                     source["hbm_bytes_per_step_all_kernels"] = float(all_k)
         except Exception as e:  # a malformed profile must not take the bench line down
-            traffic = traffic_step = frac_pmc = frac_step = None
+            traffic = frac_step = None
             source = {"file": os.path.relpath(pmc, ROOT), "stale": f"unreadable: {e}"}
-    sh_alg = SHADE_BYTES_PER_VERTEX * stc.vertices_shaded
-    sh_launches_per_step = acc["shade_launches"] / max(steps, 1)
-    sh_avg_s = (acc["shade_ms"] / 1e3) / max(acc["shade_launches"], 1)
-    sh_ach = sh_alg / max(sh_launches_per_step, 1) / sh_avg_s / 1e9 if sh_avg_s > 0 else 0.0
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "kernel": "k_trace", "avg_launch_ms": avg_launch_s * 1e3, "launches_per_step": launches_per_step,
-            "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_bytes_per_step": alg,
-            "traffic_per_step": traffic_step, "hbm_frac_rocprof": frac_pmc,
-            "hbm_frac_rocprof_step": frac_step, "traffic_source": source,
-            "bytes_per_ray": alg / max(trace_rays, 1),
-            "nodes_per_ray": (stc.nodes_fetched - stc.tail_nodes_fetched) / max(trace_rays, 1),
-            "tris_per_ray": (stc.tris_tested - stc.tail_tris_tested) / max(trace_rays, 1),
-            "rays_in_fused_tail_launch": stc.tail_rays,
-            "trace_share_of_device_time": acc["trace_ms"] / max(acc["kernel_ms"], 1e-9),
-            "kernels": {"k_shade": {
-                "bound": "hbm", "achieved": sh_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sh_ach / HBM_PEAK_GBS,
-                "avg_launch_ms": sh_avg_s * 1e3, "launches_per_step": sh_launches_per_step,
-                "algorithmic_bytes_per_step": sh_alg, "bytes_per_vertex": SHADE_BYTES_PER_VERTEX,
-                "share_of_device_time": acc["shade_ms"] / max(acc["kernel_ms"], 1e-9),
-                "note": "f64 VALU / latency bound, not byte bound (DESIGN.md section 4): the fraction is reported, "
-                        "not a target"}}}
+    top = pick_roofline(groups)
+    out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    out.update(top)
+    out.update({
+        # (the contract's `traffic`: HBM bytes per launch of the traversal kernel, whose launches are what a step is cut into)
+        "traffic": traffic, "hbm_frac_rocprof_step": frac_step, "traffic_source": source,
+        "kernels": groups,
+        "k_trace_detail": {"avg_launch_ms": avg_launch_s * 1e3, "launches_per_step": launches_per_step,
+                           "algorithmic_bytes_per_launch": alg / max(launches_per_step, 1),
+                           "bytes_per_ray": alg / max(trace_rays, 1),
+                           "nodes_per_ray": (stc.nodes_fetched - stc.tail_nodes_fetched) / max(trace_rays, 1),
+                           "tris_per_ray": (stc.tris_tested - stc.tail_tris_tested) / max(trace_rays, 1),
+                           "rays_in_fused_tail_launch": stc.tail_rays},
+    })
+    return out
 
 
 def main():
@@ -393,6 +466,34 @@ def main():
         dv[rank] = local_rank
         dist.all_reduce(dv, op=dist.ReduceOp.SUM)
         devices_all = [int(x) for x in dv.tolist()]
+    r3 = torch.tensor([float(acc["r1"]), float(acc["r2"]), float(acc["r3"])], dtype=torch.float64, device=coll_dev)
+    if world > 1:
+        dist.all_reduce(r3, op=dist.ReduceOp.SUM)
+    rays3 = [float(x) for x in r3.tolist()]
+    # the film of the last timed step on rank 0 (N > 1: gathered), as one number
+    film_hash = fnv1a_film(b.d_rgb, b.d_n) if rank == 0 else None
+    film_ok, per_rank_ms = None, None
+    if world > 1:
+        # device time of every rank's own share, and the proof that the gathered film is THE film: the same image at
+        # 1 spp rendered once by all ranks (tiles + gather) and once by rank 0 alone, compared bit for bit -- outside
+        # the timed region
+        pr = torch.zeros(world, dtype=torch.float64, device=coll_dev)
+        pr[rank] = acc["kernel_ms"] / args.steps
+        dist.all_reduce(pr, op=dist.ReduceOp.SUM)
+        per_rank_ms = [float(x) for x in pr.tolist()]
+        cfg_keep = b.cfg
+        b.cfg = rr.make_cfg(b.W, b.H, 1, seed=0, tile_rank=rank, tile_world=world, paths_in_flight=b.pif, precision=b.precision)
+        b.step()
+        if rank == 0:
+            many = (b.d_rgb.clone(), b.d_n.clone())
+            b.cfg = rr.make_cfg(b.W, b.H, 1, seed=0, paths_in_flight=b.pif, precision=b.precision)
+            g = b.gather
+            b.gather = None
+            b.step()
+            b.gather = g
+            film_ok = bool(torch.equal(many[0], b.d_rgb) and torch.equal(many[1], b.d_n))
+        b.cfg = cfg_keep
+        barrier()
     stc = b.counted()
 
     if rank == 0:
@@ -421,6 +522,11 @@ def main():
             # also paths/s and the mean path length (rays per camera sample), whole job
             "mpaths_per_s": W * H * spp * args.steps / dt_max / 1e6,
             "mean_rays_per_path": rays_all / args.steps / (W * H * spp),
+            # R1 extension incl. primary (integrator.rs:388), R2 shadow (:584), R3 MIS probe (:615), per step
+            "rays": {"extension": rays3[0] / args.steps, "shadow": rays3[1] / args.steps, "probe": rays3[2] / args.steps},
+            "film_fnv1a": film_hash,
+            "film_matches_one_rank": film_ok,
+            "per_rank_device_ms": per_rank_ms,
         }
         scene_for_cpu = b.scene
     b_main = b
@@ -435,9 +541,10 @@ def main():
             rf = roofline(e, ea, ec, esteps)
             extra.append({"workload": e.desc, "value": ea["rays"] / ea["dt"] / 1e6, "unit": "Mrays/s",
                           "ms_per_step": ea["dt"] / esteps * 1e3, "steps": esteps,
-                          "roofline": {k: rf[k] for k in ("achieved", "frac", "traffic", "hbm_frac_rocprof", "hbm_frac_rocprof_step", "traffic_source",
-                                                          "avg_launch_ms", "launches_per_step", "bytes_per_ray")},
-                          "k_shade_ms_per_step": ea["shade_ms"] / esteps, "k_trace_ms_per_step": ea["trace_ms"] / esteps})
+                          "roofline": {k: rf[k] for k in ("kernel", "achieved", "frac", "frac_is", "frac_algorithmic_incl_cache_hits",
+                                                          "hbm_frac_rocprof", "hbm_frac_rocprof_step", "traffic_source")},
+                          "k_shade_ms_per_step": ea["shade_ms"] / esteps, "k_trace_ms_per_step": ea["trace_ms"] / esteps,
+                          "k_classify_ms_per_step": ea["classify_ms"] / esteps})
             e.close()
         # the f32 fast mode on the headline workload: reported, never the headline (SURVEY.md 8d tolerance row)
         f = Bench(args.workload, 0, 1, local_rank, coll_dev, args.paths_in_flight, precision=1, ctx=b.ctx)
@@ -451,6 +558,7 @@ def main():
         extra.append({"workload": f.desc + " -- RT_PRECISION_F32 fast mode", "dtype": "f32",
                       "value": fa["rays"] / fa["dt"] / 1e6, "unit": "Mrays/s", "ms_per_step": fa["dt"] / 2 * 1e3, "steps": 2,
                       "k_shade_ms_per_step": fa["shade_ms"] / 2, "k_trace_ms_per_step": fa["trace_ms"] / 2,
+                      "k_classify_ms_per_step": fa["classify_ms"] / 2,
                       "rmse_vs_f64_same_seed": float(torch.sqrt(d2.mean() / 3.0)),
                       "rmse_vs_f64_without_top_0.01pct": float(torch.sqrt(keep.mean() / 3.0)),
                       "image_mean_f64": float(img64.mean()), "image_mean_f32": float(img32.mean()),

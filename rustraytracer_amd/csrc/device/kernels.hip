@@ -153,18 +153,20 @@ RTD void stage_line1(rt_w2* s, uint32_t rank, uint32_t slot, D3 a, D3 q3, D3 k) 
     v.x = 0ull; q[5] = v; q[6] = v; q[7] = v;
     stage_slots(s)[rank] = slot;
 }
-// lines 0 .. cnt-1 of the wave's staging area go to line `line` of their records
+// lines 0 .. cnt-1 of the wave's staging area go to line `line` of their records (eight rounds of eight lines, written out
+// so that the LDS reads of all rounds are in flight together -- as a loop every round waited for its own two LDS reads)
 RTD void stage_flush(rt_w2* s, const PathState& st, uint32_t cnt, uint32_t line) {
     wave_sync_lds();
-    const uint32_t lane = threadIdx.x & 63u, part = lane & 7u;
+    const uint32_t lane = threadIdx.x & 63u, part = lane & 7u, sub = lane >> 3;
     const uint32_t* slots = stage_slots(s);
-    for (uint32_t j0 = 0; j0 < cnt; j0 += 8u) {
-        const uint32_t j = j0 + (lane >> 3);
-        if (j < cnt) {
-            const uint32_t slot = slots[j];
-            if (slot != kNullEntry) reinterpret_cast<rt_w2*>(st.rec + (size_t)slot * kRecBytes)[line * 8u + part] = s[j * kStagePitch + part];
-        }
-    }
+    char* base = st.rec + (size_t)(line * 8u + part) * 16u;
+    const rt_w2* row = s + sub * kStagePitch + part;
+#define RT_FLUSH_LD(k) const uint32_t s##k = (k) * 8u + sub < cnt ? slots[(k) * 8 + sub] : kNullEntry; const rt_w2 v##k = row[(k) * 8 * kStagePitch];
+    RT_FLUSH_LD(0) RT_FLUSH_LD(1) RT_FLUSH_LD(2) RT_FLUSH_LD(3) RT_FLUSH_LD(4) RT_FLUSH_LD(5) RT_FLUSH_LD(6) RT_FLUSH_LD(7)
+#undef RT_FLUSH_LD
+#define RT_FLUSH_ST(k) if (s##k != kNullEntry) *reinterpret_cast<rt_w2*>(base + (size_t)s##k * kRecBytes) = v##k;
+    RT_FLUSH_ST(0) RT_FLUSH_ST(1) RT_FLUSH_ST(2) RT_FLUSH_ST(3) RT_FLUSH_ST(4) RT_FLUSH_ST(5) RT_FLUSH_ST(6) RT_FLUSH_ST(7)
+#undef RT_FLUSH_ST
     wave_sync_lds();  // (the area is reused)
 }
 // the reverse: line `line` of record `slot` (kNullEntry: none) of every lane arrives at that lane's rank = lane
@@ -654,36 +656,34 @@ __global__ __launch_bounds__(256) void k_classify_count(const uint32_t* __restri
         for (int c = 0; c < kMaxCls; c++) counts[(uint32_t)c * n_waves + wave_g] = cnt[c];
     }
 }
-// one block of 1024 threads: exclusive prefix of every class's counts over the waves (in place), totals -> list lengths
+// one block of 1024 threads = 8 classes x 128 threads: exclusive prefix of every class's counts over the waves (in place),
+// totals -> list lengths.  A thread sums a run of consecutive waves, the 128 run sums of a class are scanned through LDS
+// (7 steps), the thread walks its run again with the running prefix.
 template <int DUMMY>
 __global__ __launch_bounds__(1024) void k_classify_scan(uint32_t* counts, uint32_t n_waves, Ctl* ctl, uint32_t it_abs) {
-    __shared__ uint32_t s_part[1024];
-    const uint32_t per = (n_waves + 1023u) / 1024u;  // <= 8
-    for (uint32_t c = 0; c < (uint32_t)kMaxCls; c++) {
-        uint32_t* row = counts + c * n_waves;
-        uint32_t v[8], sum = 0;
-        for (uint32_t k = 0; k < per; k++) {
-            const uint32_t i = threadIdx.x * per + k;
-            v[k] = i < n_waves ? row[i] : 0u;
-            sum += v[k];
-        }
-        s_part[threadIdx.x] = sum;
+    static_assert(kMaxCls == 8, "one 128-thread group per class");
+    __shared__ uint32_t s_part[kMaxCls][128];
+    const uint32_t c = threadIdx.x >> 7, j = threadIdx.x & 127u;
+    const uint32_t per = (n_waves + 127u) / 128u;
+    uint32_t* row = counts + c * n_waves;
+    const uint32_t lo = j * per, hi = lo + per < n_waves ? lo + per : n_waves;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += row[i];
+    s_part[c][j] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 128u; d <<= 1) {
+        const uint32_t add = j >= d ? s_part[c][j - d] : 0u;
         __syncthreads();
-        for (uint32_t d = 1; d < 1024u; d <<= 1) {  // Hillis-Steele over the 1024 partial sums
-            const uint32_t add = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0u;
-            __syncthreads();
-            s_part[threadIdx.x] += add;
-            __syncthreads();
-        }
-        uint32_t run = threadIdx.x ? s_part[threadIdx.x - 1] : 0u;
-        for (uint32_t k = 0; k < per; k++) {
-            const uint32_t i = threadIdx.x * per + k;
-            if (i < n_waves) row[i] = run;
-            run += v[k];
-        }
-        if (threadIdx.x == 1023u) ctl->cls_count[it_abs & 3u][c][0] = s_part[1023];
+        s_part[c][j] += add;
         __syncthreads();
     }
+    uint32_t run = j ? s_part[c][j - 1] : 0u;
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t v = row[i];
+        row[i] = run;
+        run += v;
+    }
+    if (j == 127u) ctl->cls_count[it_abs & 3u][c][0] = s_part[c][127];
 }
 template <int DUMMY>
 __global__ __launch_bounds__(256) void k_classify_scatter(const uint32_t* __restrict__ queue, const uint32_t* __restrict__ hitw, PathState st,

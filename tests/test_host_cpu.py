@@ -497,3 +497,23 @@ def test_c_host_compiles_as_c99_and_fails_loudly_without_a_device(tmp_path):
         assert r.returncode == 1 and "no HIP device" in r.stdout, r.stdout
     else:
         assert "film_fnv" in r.stdout
+
+
+def test_bench_names_the_kernel_with_the_largest_share_and_never_reports_a_fraction_above_one():
+    """bench.py: pick_roofline -- `kernel` = largest share of device time; `frac` = the measured HBM
+    fraction when the counter profile is current, else the algorithmic one, and never an algorithmic figure above 1."""
+    import bench
+    ks = {"k_trace": {"share_of_device_time": 0.45, "frac_algorithmic": 1.2, "hbm_frac_rocprof": 0.47, "hbm_read_frac_rocprof": 0.44, "achieved": 9600.0},
+          "k_shade": {"share_of_device_time": 0.51, "frac_algorithmic": 0.46, "hbm_frac_rocprof": 0.31, "hbm_read_frac_rocprof": 0.2, "achieved": 3700.0},
+          "k_classify": {"share_of_device_time": 0.04, "frac_algorithmic": 0.5, "hbm_frac_rocprof": None, "achieved": 4000.0}}
+    top = bench.pick_roofline(ks)
+    assert top["kernel"] == "k_shade" and top["frac"] == 0.31 and top["frac_algorithmic_incl_cache_hits"] == 0.46
+    ks["k_trace"]["share_of_device_time"] = 0.6
+    top = bench.pick_roofline(ks)
+    assert top["kernel"] == "k_trace" and top["frac"] == 0.47 and top["frac_algorithmic_incl_cache_hits"] == 1.2
+    ks["k_trace"]["hbm_frac_rocprof"] = None  # stale / missing counter profile: an algorithmic 1.2 is not a fraction
+    top = bench.pick_roofline(ks)
+    assert top["frac"] is None and top["frac_algorithmic_incl_cache_hits"] == 1.2 and "withheld" in top["frac_is"]
+    ks["k_trace"]["frac_algorithmic"] = 0.8
+    assert bench.pick_roofline(ks)["frac"] == 0.8
+

@@ -57,6 +57,8 @@ def stage(tag):
         "hbm_bytes_per_step_all_kernels": step_rd + step_wr,
         "hbm_read_bytes_per_step_all_kernels": step_rd, "hbm_write_bytes_per_step_all_kernels": step_wr,
         "per_kernel_hbm_bytes_per_step": {k: r + w for k, (r, w) in per_kernel.items()},
+        "per_kernel_hbm_read_bytes_per_step": {k: r for k, (r, w) in per_kernel.items()},
+        "per_kernel_hbm_write_bytes_per_step": {k: w for k, (r, w) in per_kernel.items()},
         "kernel": key, "workload": tag, "launches": n,
         "FETCH_SIZE_KB_sum": t["FETCH_SIZE"], "WRITE_SIZE_KB_sum": t["WRITE_SIZE"],
         "hbm_read_bytes_per_launch_raw": rd_raw,
@@ -97,8 +99,8 @@ def collect(tag, rnd):
     for r in csv.DictReader(open(ks[0])):
         if "k_trace" in r["Name"]:
             print("rocprof k_trace avg ms", float(r["AverageNs"]) / 1e6, "calls", r["Calls"],
-                  "| bench-under-rocprof avg_launch_ms", sb["roofline"]["avg_launch_ms"],
-                  "| plain bench avg_launch_ms", b["roofline"]["avg_launch_ms"])
+                  "| bench-under-rocprof avg_launch_ms", sb["roofline"]["k_trace_detail"]["avg_launch_ms"],
+                  "| plain bench avg_launch_ms", b["roofline"]["k_trace_detail"]["avg_launch_ms"])
     print(json.dumps({k: b[k] for k in ("value", "ms_per_step", "roofline", "cpu_baseline")}, indent=1))
 
 

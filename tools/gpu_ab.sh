@@ -7,7 +7,7 @@ for wl in "$@"; do for lib in "" $V; do
   python - $wl "${lib:-base}" <<'PY'
 import json,sys,os
 d=json.load(open('gpurun_out/tmp.json'))
-r=d['roofline']; k=r['kernels']['k_shade']
-print('%s %-8s Mrays/s %.0f ms %.2f trace %.2f shade %.2f | nodes/ray %.3f prims/ray %.3f alg GB/s %.0f'%(sys.argv[1],os.path.basename(sys.argv[2])[:8],d['value'],d['ms_per_step'],r['avg_launch_ms']*r['launches_per_step'],k['avg_launch_ms']*k['launches_per_step'],r['nodes_per_ray'],r['tris_per_ray'],r['achieved']))
+r=d['roofline']; K=r['kernels']
+print('%s %-8s Mrays/s %.0f ms %.2f trace %.2f classify %.2f shade %.2f | nodes/ray %.3f prims/ray %.3f'%(sys.argv[1],os.path.basename(sys.argv[2])[:8],d['value'],d['ms_per_step'],K['k_trace']['ms_per_step'],K['k_classify']['ms_per_step'],K['k_shade']['ms_per_step'],r['k_trace_detail']['nodes_per_ray'],r['k_trace_detail']['tris_per_ray']))
 PY
 done; done

@@ -7,7 +7,7 @@ for wl in "$@"; do
   python - $wl <<'PY'
 import json,sys
 d=json.load(open('gpurun_out/tmp.json'))
-r=d['roofline']; k=r['kernels']['k_shade']
-print('%s Mrays/s %.0f ms %.2f trace %.2f shade %.2f'%(sys.argv[1],d['value'],d['ms_per_step'],r['avg_launch_ms']*r['launches_per_step'],k['avg_launch_ms']*k['launches_per_step']))
+r=d['roofline']; K=r['kernels']
+print('%s Mrays/s %.0f ms %.2f trace %.2f classify %.2f shade %.2f'%(sys.argv[1],d['value'],d['ms_per_step'],K['k_trace']['ms_per_step'],K['k_classify']['ms_per_step'],K['k_shade']['ms_per_step']))
 PY
 done
