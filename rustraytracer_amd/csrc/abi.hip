@@ -163,8 +163,9 @@ static void pool_layout(uint32_t cap, uint32_t n_cls, size_t& slots, size_t& qn,
     // of a launch's entries per kernel (kernels.hip: pick_chunk), summed generously
     slots = (size_t)cap + cap / 8 + 65536;
     qn = 3 * slots;
-    // per slot and pool: the 256-B record + 12 ray words + 2 result words; 2 fold lists; per queue entry: 2 queues + hit words
-    bytes = slots * (2 * ((size_t)kRecBytes + 12 * 8 + 2 * 4) + 2 * sizeof(uint32_t)) + 3 * qn * sizeof(uint32_t) +
+    // per slot and pool: the 256-B record + 12 ray words + 2 result words + the camera sample's RNG state; 2 fold lists;
+    // per queue entry: 2 queues + hit words
+    bytes = slots * (2 * ((size_t)kRecBytes + 12 * 8 + 2 * 4 + 8) + 2 * sizeof(uint32_t)) + 3 * qn * sizeof(uint32_t) +
             (size_t)n_cls * slots * sizeof(ListEnt) + 4096;
 }
 
@@ -200,6 +201,7 @@ static int ensure_lane_capacity(rt_context* c, Lane& ln, uint32_t cap, uint32_t 
             *dp = (double*)p;
             p += slots * 8;
         }
+        st.rng0 = (uint64_t*)p; p += slots * 8;
         st.sh_prim = (int32_t*)p; p += slots * 4;
         st.pr_prim = (int32_t*)p; p += slots * 4;
     }
@@ -1124,13 +1126,12 @@ static int run_lane(RenderJob& job, int lane_id) {
         }
         // one kernel per vertex class, the heaviest instances first; then the paths that end without a vertex (escaped,
         // fold only).  Persistent grids: a class with few paths this bounce costs a launch, not a grid of empty blocks.
-        const CamArgs cam_args{job.cam, job.batch, c->pix_list};  // (a camera sample's first vertex: scene_dev.h, kEntFresh)
         for (uint32_t k = 1; k < job.s->n_cls; k++)
             hipLaunchKernelGGL(shade_cls_kernel(job.s->cls[k], job.f32_shade), dim3(std::min(shade_want, (uint32_t)job.shade_blocks[k])), dim3(256), 0,
                                stream, job.s->dev, ln.st[it & 1], ln.st[(it + 1) & 1], ln.ctl, (uint32_t)it, cfg->max_depth, ln.lists, k,
-                               ln.queue[(it + 1) & 1], ln.q_cap, ln.slot_cap, c->lf, c->stats, cam_args);
+                               ln.queue[(it + 1) & 1], ln.q_cap, ln.slot_cap, c->lf, c->stats);
         hipLaunchKernelGGL(shade_light_kernel(job.s->dev.env.light >= 0, job.f32_shade), dim3(std::min(shade_want, (uint32_t)job.shade_blocks[0])), dim3(256),
-                           0, stream, job.s->dev, ln.st[it & 1], ln.ctl, (uint32_t)it, cfg->max_depth, ln.lists, c->lf, cam_args);
+                           0, stream, job.s->dev, ln.st[it & 1], ln.ctl, (uint32_t)it, cfg->max_depth, ln.lists, c->lf);
         if (!no_ev) {  // the shading kernel runs from event b (end of k_trace) to this one
             hipEvent_t e = get_event(ln.events, ln.ev_i++);
             if (!e) {

@@ -252,8 +252,7 @@ RTD void cursor_pad(const Cursor& c, uint32_t* arr, uint32_t cap) {
 RTD DevStats* stat_shard(DevStats* stats) { return stats + (blockIdx.x & (kStatShards - 1)); }
 
 // One camera sample of the batch: integrator.rs:357-366 + sampler.rs:606-613 + geometry.rs:177-190 (+ util.rs:105-113).
-// g = its index in the batch = its film staging slot.  Run by k_generate (the ray) and again by the kernel that shades
-// the sample's first vertex (ray, RNG state), which is cheaper than carrying a 128-B record line from one to the other.
+// g = its index in the batch = its film staging slot.
 RTD void camera_sample(const rt_camera& cam, const ChunkDesc& ck, const uint32_t* __restrict__ pix_list, uint32_t g, D3& o, D3& d,
                        uint64_t& rng_out) {
     const uint32_t s_local = g / ck.n_pixels, p_local = g - s_local * ck.n_pixels;
@@ -340,6 +339,7 @@ __global__ __launch_bounds__(256) void k_generate(PathState st, rt_camera cam, C
     camera_sample(cam, ck, pix_list, g, o, d, rng);
     st3(st.ox, st.oy, st.oz, slot, o);
     st3(st.dx, st.dy, st.dz, slot, d);
+    st.rng0[slot] = rng;
     queue[ctl->gen_q + idx] = slot | (kRayExt << 30);
 }
 #endif  // RT_KERNELS_CORE
@@ -668,6 +668,7 @@ __global__ __launch_bounds__(1024) void k_classify_scan(uint32_t* counts, uint32
     uint32_t* row = counts + c * n_waves;
     const uint32_t lo = j * per, hi = lo + per < n_waves ? lo + per : n_waves;
     uint32_t sum = 0;
+#pragma unroll 16
     for (uint32_t i = lo; i < hi; i++) sum += row[i];
     s_part[c][j] = sum;
     __syncthreads();
@@ -678,6 +679,7 @@ __global__ __launch_bounds__(1024) void k_classify_scan(uint32_t* counts, uint32
         __syncthreads();
     }
     uint32_t run = j ? s_part[c][j - 1] : 0u;
+#pragma unroll 16
     for (uint32_t i = lo; i < hi; i++) {
         const uint32_t v = row[i];
         row[i] = run;
@@ -763,11 +765,18 @@ struct ShadeA {
 RTD bool rec_wants_line1(const RecRegs& R, bool valid, bool pending) {
     return valid && pending && ((uint32_t)(R.p[3].y >> 32) & (kHasShadow | kHasProbe)) != 0u;
 }
-// line 0 of a camera sample that has not been shaded yet (scene_dev.h: kEntFresh): beta = 1, L = 0, no flags
-RTD void rec_fresh(const CamArgs& ca, uint32_t g, RecRegs& R) {
-    D3 o, d;
-    uint64_t rng;
-    camera_sample(ca.cam, ca.ck, ca.pix_list, g, o, d, rng);
+// line 0 of a camera sample that has not been shaded yet (scene_dev.h: kEntFresh): ray and RNG state where k_generate
+// left them, beta = 1, L = 0, no flags
+template <bool RAY>
+RTD void rec_fresh(const PathState& in, uint32_t slot, uint32_t g, RecRegs& R) {
+    // (RAY = false: an escaped camera sample without an environment to see needs nothing but its film slot)
+    D3 o = black(), d = black();
+    uint64_t rng = 0;
+    if (RAY) {
+        o = ld3(in.ox, in.oy, in.oz, slot);
+        d = ld3(in.dx, in.dy, in.dz, slot);
+        rng = in.rng0[slot];
+    }
     R.p[0].x = r2w(o.x); R.p[0].y = r2w(o.y);
     R.p[1].x = r2w(o.z); R.p[1].y = r2w(d.x);
     R.p[2].x = r2w(d.y); R.p[2].y = r2w(d.z);
@@ -776,8 +785,8 @@ RTD void rec_fresh(const CamArgs& ca, uint32_t g, RecRegs& R) {
     R.p[5].x = r2w(1.0); R.p[5].y = r2w(0.0);
     R.p[6].x = r2w(0.0); R.p[6].y = r2w(0.0);
 }
-RTD void rec_fetch(rt_w2* stage, const PathState& in, uint32_t slot, bool valid, bool pending, bool fresh, uint32_t fresh_g, const CamArgs& ca,
-                   RecRegs& R) {
+template <bool RAY>
+RTD void rec_fetch(rt_w2* stage, const PathState& in, uint32_t slot, bool valid, bool pending, bool fresh, uint32_t fresh_g, RecRegs& R) {
     const uint32_t lane = threadIdx.x & 63u;
     const bool stored = valid && !fresh;
     if (__ballot(stored)) {
@@ -785,7 +794,7 @@ RTD void rec_fetch(rt_w2* stage, const PathState& in, uint32_t slot, bool valid,
 #pragma unroll
         for (int k = 0; k < 7; k++) R.p[k] = stage[lane * kStagePitch + k];
     }
-    if (valid && fresh) rec_fresh(ca, fresh_g, R);
+    if (valid && fresh) rec_fresh<RAY>(in, slot, fresh_g, R);
     const bool fold = rec_wants_line1(R, valid, pending);
     if (__ballot(fold)) {
         wave_sync_lds();  // (every lane has read its line 0)
@@ -1069,7 +1078,7 @@ RTD void rec_store_direct(const PathState& out, uint32_t os, const ShadeA& a, co
 template <int FEAT, int KIND>
 __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade_cls(DevScene sc, PathState in, PathState out, Ctl* ctl, uint32_t it_abs,
                                                uint32_t max_depth, Lists lists, uint32_t cls, uint32_t* queue_out, uint32_t q_cap,
-                                               uint32_t slot_cap, f64_t* lf, DevStats* stats, CamArgs ca) {
+                                               uint32_t slot_cap, f64_t* lf, DevStats* stats) {
     const uint32_t itn = (it_abs + 1) % kRing;
     const uint32_t n = ctl->cls_count[it_abs & 3u][cls][0];
     const uint32_t n_groups = (n + 63u) / 64u;
@@ -1099,7 +1108,7 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade_cls(DevScen
         // ---- records in
         const bool pending = valid && (e.slot & kEntPending), fresh = valid && (e.slot & kEntFresh);
         RecRegs R{};
-        rec_fetch(stage, in, e.slot & kSlotMask, valid, pending, fresh, (uint32_t)e.sh, ca, R);
+        rec_fetch<true>(stage, in, e.slot & kSlotMask, valid, pending, fresh, (uint32_t)e.sh, R);
         // ---- compute
         ShadeA a{};
         shade_a<FEAT, KIND>(sc, in, R, e.slot & kSlotMask, e.hit, true, e.sh, e.pr, pending, valid, max_depth, a);
@@ -1173,7 +1182,7 @@ __global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade_cls(DevScen
 // of the environment, film staging -- a few dozen registers, one whole line of the record for most of them.
 template <int FEAT>
 __global__ __launch_bounds__(256, 4) void k_shade_light(DevScene sc, PathState in, Ctl* ctl, uint32_t it_abs, uint32_t max_depth,
-                                                     Lists lists, f64_t* lf, CamArgs ca) {
+                                                     Lists lists, f64_t* lf) {
     const uint32_t n0 = ctl->cls_count[it_abs & 3u][0][0], n1 = ctl->fold_count[it_abs & 3u][0];
     const uint32_t g0 = (n0 + 63u) / 64u, n_groups = g0 + (n1 + 63u) / 64u;
     const uint32_t lane = threadIdx.x & 63u, n_waves = gridDim.x * (blockDim.x >> 6);
@@ -1205,7 +1214,7 @@ __global__ __launch_bounds__(256, 4) void k_shade_light(DevScene sc, PathState i
         }
         const bool valid = slot != kNullEntry;
         RecRegs R{};
-        rec_fetch(stage, in, slot & kSlotMask, valid, pending, fresh, (uint32_t)sh, ca, R);
+        rec_fetch<(FEAT & kFeatEnv) != 0>(stage, in, slot & kSlotMask, valid, pending, fresh, (uint32_t)sh, R);
         ShadeA a{};
         shade_a<FEAT, kKindNone>(sc, in, R, slot & kSlotMask, 0u, false, sh, pr, pending, valid, max_depth, a);
         if (a.live) film_put(lf, a.orig, a.L);

@@ -131,6 +131,7 @@ struct PathState {
     double *pdx, *pdy, *pdz;  // MIS probe direction
     int32_t* sh_prim;         // closest prim along the shadow ray (Q13)
     int32_t* pr_prim;         // closest prim along the probe ray
+    uint64_t* rng0;           // RNG state of a camera sample after its camera draws (k_generate; see kEntFresh)
 };
 constexpr uint32_t kRecBytes = 256;
 constexpr int kWO = 0, kWD = 3, kWRng = 6, kWMeta = 7, kWBeta = 8, kWL = 11, kWA = 16, kWQ = 19, kWK = 22;
@@ -149,9 +150,10 @@ constexpr uint32_t kRayExt = 0u, kRayShadow = 1u, kRayProbe = 2u, kRayNone = 3u;
 constexpr uint32_t kSlotMask = 0x1fffffffu, kQPending = 1u << 29;
 constexpr uint32_t kNullEntry = 0xffffffffu;  // unused queue / list entry
 constexpr uint32_t kEntPending = 1u << 30;    // in ListEnt::slot
-// A camera sample has no record until its first vertex is shaded: everything in it follows from its index in the batch
-// (kernels.hip: camera_sample), which k_classify hands on in ListEnt::sh.  k_generate writes the ray only -- 52 B per
-// sample instead of 180, and the shading kernels do not fetch 128 B that say "beta = 1, L = 0".
+// A camera sample has no record until its first vertex is shaded: its ray is in the ray arrays, the state of its RNG in
+// rng0[], its film slot = its index in the batch, which k_classify hands on in ListEnt::sh; beta = 1, L = 0.  k_generate
+// writes 60 B per sample instead of 180, and the shading kernels do not fetch 128 B that mostly say "one" and "zero"
+// (the lists keep the queue's order, so a wave's camera samples sit in nearly consecutive slots: these reads coalesce).
 constexpr uint32_t kEntFresh = 1u << 29;
 
 // ---- vertex classes (round 4).  Every primitive belongs to a class = (smallest shading-kernel instance that covers its
@@ -222,13 +224,6 @@ struct ChunkDesc {
     uint32_t sample_base;  // first sample index
     uint32_t width, height;
     uint64_t seed;
-};
-
-// what a shading kernel needs to run a camera sample again (kernels.hip: camera_sample, scene_dev.h: kEntFresh)
-struct CamArgs {
-    rt_camera cam;
-    ChunkDesc ck;
-    const uint32_t* pix_list;
 };
 
 struct TraceTune {

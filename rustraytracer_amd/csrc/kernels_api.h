@@ -14,8 +14,8 @@ using namespace rtc;
 constexpr int kVariants = 9;  // shading.h: kNumFeatVariants
 
 typedef void (*ShadeClsKernel)(DevScene, PathState, PathState, Ctl*, uint32_t, uint32_t, Lists, uint32_t, uint32_t*, uint32_t,
-                               uint32_t, double*, DevStats*, CamArgs);
-typedef void (*ShadeLightKernel)(DevScene, PathState, Ctl*, uint32_t, uint32_t, Lists, double*, CamArgs);
+                               uint32_t, double*, DevStats*);
+typedef void (*ShadeLightKernel)(DevScene, PathState, Ctl*, uint32_t, uint32_t, Lists, double*);
 typedef void (*TailKernel)(DevScene, PathState, PathState, Ctl*, uint32_t, uint32_t, const uint32_t*, Lists, double*, DevStats*);
 typedef void (*TraceKernel)(DevScene, PathState, const uint32_t*, Ctl*, uint32_t, DevStats*, TraceTune, MirrorEntry*, uint32_t,
                             const BatchCtl*, unsigned long long, uint32_t*);
