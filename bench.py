@@ -432,10 +432,12 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        from rustraytracer_amd import dist as rd_
+        # (bounded collective timeout: a rank that fails takes the whole job down within RT_DIST_TIMEOUT_S, default 600 s)
         if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            rd_.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend="gloo")
+            rd_.init_process_group("gloo")
     coll_dev = "cuda" if args.backend == "nccl" else "cpu"
     # N ranks commit the same scene: the host BVH is built once per node and shared through /dev/shm (abi.hip:
     # build_bvh_shared) instead of N simultaneous 16-thread SAH builds; rank 0 removes the files at the end
@@ -580,4 +582,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        from rustraytracer_amd.dist import run_guarded
+        run_guarded(main)  # any rank's failure = exit code 1 of that rank at once; the others follow (timeout / torchrun)
+    else:
+        main()

@@ -1058,7 +1058,10 @@ RTD void rec_store_direct(const PathState& out, uint32_t os, const ShadeA& a, co
                              // two-lobe and row-f4 instances spill too much to gain from it)
 #endif
 #undef RT_SHADE_BOUND
-#define RT_SHADE_BOUND_RULE(F) (feat_three_waves(F) && RT_SHADE3_MAXFEAT >= 3 ? 3 : RT_SHADE_WAVES)
+#ifndef RT_SHADE_FEAT0_WAVES
+#define RT_SHADE_FEAT0_WAVES 3  // (experiment) the Lambert-only instances at 2 waves/SIMD: no spills, a third fewer waves
+#endif
+#define RT_SHADE_BOUND_RULE(F) ((F) == 0 ? RT_SHADE_FEAT0_WAVES : (feat_three_waves(F) && RT_SHADE3_MAXFEAT >= 3 ? 3 : RT_SHADE_WAVES))
 #ifdef RT_F32
 #ifndef RT_F32_SHADE_WAVES
 #define RT_F32_SHADE_WAVES 4  // the binary32 single-lobe instances need 127-138 VGPRs: 4 waves/SIMD with a few spills

@@ -18,6 +18,37 @@ import torch.distributed as dist
 TILE_SIZE = 16  # src/consts.rs:10
 
 
+def init_process_group(backend, device_id=None, timeout_s=None):
+    """torch.distributed.init_process_group with a BOUNDED collective timeout (RT_DIST_TIMEOUT_S, default 600 s): when a
+    rank dies -- a HIP or RCCL error, an exception anywhere -- the others' next collective fails within that time instead of
+    waiting for it forever, and every process of the job exits non-zero (bench.py: run_guarded).  Under torchrun the agent
+    also ends the other workers as soon as one exits with an error."""
+    import datetime
+    import os
+    t = float(timeout_s if timeout_s is not None else os.environ.get("RT_DIST_TIMEOUT_S", "600"))
+    kw = {"timeout": datetime.timedelta(seconds=t)}
+    if device_id is not None:
+        kw["device_id"] = device_id
+    dist.init_process_group(backend=backend, **kw)
+
+
+def run_guarded(fn):
+    """Run fn(); any exception -> its message with the rank on stderr, exit code 1 at once (os._exit: no atexit handler may
+    sit in a collective the failed rank will never join)."""
+    import os
+    import sys
+    import traceback
+    try:
+        return fn()
+    except SystemExit:
+        raise
+    except BaseException:  # noqa: BLE001 -- the job must come down whatever it was
+        sys.stderr.write("[rank %s] failed:\n%s" % (os.environ.get("RANK", "0"), traceback.format_exc()))
+        sys.stderr.flush()
+        sys.stdout.flush()
+        os._exit(1)
+
+
 def tile_stride(world):
     """include/rt_abi.h: rt_tile_stride -- the integer nearest to world / golden ratio that is coprime to world."""
     if world <= 1:

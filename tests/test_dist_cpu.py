@@ -120,3 +120,43 @@ def test_tile_owner_rule_matches_the_exported_function():
     # 120 tiles per row, 8 ranks: a rank's tiles are not whole columns
     cols = {tx for ty in range(68) for tx in range(120) if rd.tile_owner(tx, ty, 8) == 3}
     assert len(cols) == 120
+
+
+FAILING_WORKER = r'''
+import os, sys, time
+import torch, torch.distributed as dist
+sys.path.insert(0, os.environ["RR_ROOT"])
+from rustraytracer_amd import dist as rd
+rank = int(os.environ["RANK"])
+def job():
+    rd.init_process_group("gloo")
+    g = rd.FilmGather(64, 32, "cpu")
+    rgb, n = torch.zeros((32, 64, 3), dtype=torch.float64), torch.zeros((32, 64), dtype=torch.int32)
+    if rank == 1:
+        raise RuntimeError("simulated HIP error on rank 1")  # (what rt_render's RtError looks like to the caller)
+    g.gather(rgb, n)  # rank 0 waits for a payload that never comes (a non-root rank only sends)
+    dist.barrier()    # ... and every rank for rank 1, as bench.py's timing barrier does
+    print("UNREACHABLE", flush=True)
+rd.run_guarded(job)
+'''
+
+
+def test_a_failing_rank_takes_the_job_down_within_the_timeout():
+    """VERDICT r3 item 8: one rank's failure must end every process of the job with a non-zero exit code in bounded time
+    (no rank may sit in the film gather forever).  Three gloo ranks, rank 1 raises before the gather."""
+    import time
+    port = _free_port()
+    t0 = time.time()
+    procs = []
+    for r in range(3):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RR_ROOT=ROOT,
+                   RT_DIST_TIMEOUT_S="20")
+        procs.append(subprocess.Popen([sys.executable, "-c", FAILING_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    took = time.time() - t0
+    for p, o in zip(procs, outs):
+        assert p.returncode != 0, o[-2000:]
+        assert "UNREACHABLE" not in o
+    assert "simulated HIP error on rank 1" in outs[1]
+    assert took < 200, took
+
