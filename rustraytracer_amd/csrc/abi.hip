@@ -135,6 +135,7 @@ struct rt_scene {
     // vertex classes (scene_dev.h): class 0 = escaped; cls[k] for k >= 1 = {kernel instance, kind of hit record}
     uint32_t n_cls = 1;
     ClsDesc cls[kMaxCls] = {};
+    bool all_lambert = false;  // every class runs the Lambert-only instance (then its 2-waves/SIMD build: kernels.hip)
     // device
     std::vector<void*> allocs;
     DevScene dev{};
@@ -740,6 +741,8 @@ static int commit_to(rt_scene* s, rt_scene* t, uint32_t flags, HostLeafData& cac
             }
             if (ok && !(pass == 0 && one_class)) break;
         }
+        t->all_lambert = !getenv("RT_NO_LAMBERT_W2");
+        for (uint32_t k = 1; k < t->n_cls; k++) t->all_lambert = t->all_lambert && t->cls[k].variant == 0;
     }
     uint64_t n_tri = 0;
     uint32_t depth = 0;
@@ -989,7 +992,10 @@ using rtk::ShadeLightKernel;
 using rtk::TailKernel;
 using rtk::TraceKernel;
 using rtk::GenKernel;
-static ShadeClsKernel shade_cls_kernel(const ClsDesc& cd, bool f32) { return rtk::kernel_table().shade_cls[f32 ? 1 : 0][cd.variant][cd.kind]; }
+static ShadeClsKernel shade_cls_kernel(const ClsDesc& cd, bool f32, bool all_lambert) {
+    if (all_lambert && cd.variant == 0) return rtk::kernel_table().shade_cls_w2[f32 ? 1 : 0][cd.kind];
+    return rtk::kernel_table().shade_cls[f32 ? 1 : 0][cd.variant][cd.kind];
+}
 static ShadeLightKernel shade_light_kernel(bool env, bool f32) { return rtk::kernel_table().shade_light[f32 ? 1 : 0][env ? 1 : 0]; }
 static TailKernel tail_kernel(int v, bool count, bool f32) { return rtk::kernel_table().tail[f32 ? 1 : 0][v][count ? 1 : 0]; }
 static TraceKernel trace_kernel(bool count, bool simple, bool f32) { return rtk::kernel_table().trace[f32 ? 1 : 0][count ? 2 : (simple ? 0 : 1)]; }
@@ -1110,7 +1116,7 @@ static int run_lane(RenderJob& job, int lane_id) {
             const uint32_t cblocks = std::min((3u * bound_active + 255u) / 256u + 1u, std::min((uint32_t)c->num_cus * 8u, 8192u / 4u));
             hipLaunchKernelGGL(rtk::kernel_table().classify_count, dim3(cblocks), dim3(256), 0, stream, ln.queue[it & 1], ln.hitw, ln.ctl,
                                (uint32_t)it, ln.cls_tab);
-            hipLaunchKernelGGL(rtk::kernel_table().classify_scan, dim3(1), dim3(1024), 0, stream, ln.cls_tab, cblocks * 4u, ln.ctl, (uint32_t)it);
+            hipLaunchKernelGGL(rtk::kernel_table().classify_scan, dim3(1), dim3(512), 0, stream, ln.cls_tab, cblocks * 4u, ln.ctl, (uint32_t)it);
             hipLaunchKernelGGL(rtk::kernel_table().classify_scatter, dim3(cblocks), dim3(256), 0, stream, ln.queue[it & 1], ln.hitw, ln.st[it & 1],
                                ln.ctl, (uint32_t)it, ln.cls_tab, ln.lists);
         }
@@ -1127,7 +1133,7 @@ static int run_lane(RenderJob& job, int lane_id) {
         // one kernel per vertex class, the heaviest instances first; then the paths that end without a vertex (escaped,
         // fold only).  Persistent grids: a class with few paths this bounce costs a launch, not a grid of empty blocks.
         for (uint32_t k = 1; k < job.s->n_cls; k++)
-            hipLaunchKernelGGL(shade_cls_kernel(job.s->cls[k], job.f32_shade), dim3(std::min(shade_want, (uint32_t)job.shade_blocks[k])), dim3(256), 0,
+            hipLaunchKernelGGL(shade_cls_kernel(job.s->cls[k], job.f32_shade, job.s->all_lambert), dim3(std::min(shade_want, (uint32_t)job.shade_blocks[k])), dim3(256), 0,
                                stream, job.s->dev, ln.st[it & 1], ln.st[(it + 1) & 1], ln.ctl, (uint32_t)it, cfg->max_depth, ln.lists, k,
                                ln.queue[(it + 1) & 1], ln.q_cap, ln.slot_cap, c->lf, c->stats);
         hipLaunchKernelGGL(shade_light_kernel(job.s->dev.env.light >= 0, job.f32_shade), dim3(std::min(shade_want, (uint32_t)job.shade_blocks[0])), dim3(256),
@@ -1290,7 +1296,7 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
             if (k == 0)
                 HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&so, shade_light_kernel(s->dev.env.light >= 0, job.f32), 256, 0));
             else
-                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&so, shade_cls_kernel(s->cls[k], job.f32), 256, 0));
+                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&so, shade_cls_kernel(s->cls[k], job.f32, s->all_lambert), 256, 0));
             job.shade_blocks[k] = c->num_cus * std::max(1, so);
         }
         size_t ev_i = 0;

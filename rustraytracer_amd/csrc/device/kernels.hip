@@ -656,36 +656,35 @@ __global__ __launch_bounds__(256) void k_classify_count(const uint32_t* __restri
         for (int c = 0; c < kMaxCls; c++) counts[(uint32_t)c * n_waves + wave_g] = cnt[c];
     }
 }
-// one block of 1024 threads = 8 classes x 128 threads: exclusive prefix of every class's counts over the waves (in place),
-// totals -> list lengths.  A thread sums a run of consecutive waves, the 128 run sums of a class are scanned through LDS
-// (7 steps), the thread walks its run again with the running prefix.
+// one block of 8 waves, a wave per class: exclusive prefix of the class's counts over the waves (in place), total -> list
+// length.  64 counts per step, prefix inside the step by six shuffles, the running total carried along -- no block barrier
+// (a first version scanned through LDS with 160 of them: 69 us per launch, 2 % of a C2 frame).
 template <int DUMMY>
-__global__ __launch_bounds__(1024) void k_classify_scan(uint32_t* counts, uint32_t n_waves, Ctl* ctl, uint32_t it_abs) {
-    static_assert(kMaxCls == 8, "one 128-thread group per class");
-    __shared__ uint32_t s_part[kMaxCls][128];
-    const uint32_t c = threadIdx.x >> 7, j = threadIdx.x & 127u;
-    const uint32_t per = (n_waves + 127u) / 128u;
+__global__ __launch_bounds__(512) void k_classify_scan(uint32_t* counts, uint32_t n_waves, Ctl* ctl, uint32_t it_abs) {
+    static_assert(kMaxCls == 8, "one wave per class");
+    const uint32_t c = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint32_t* row = counts + c * n_waves;
-    const uint32_t lo = j * per, hi = lo + per < n_waves ? lo + per : n_waves;
-    uint32_t sum = 0;
-#pragma unroll 16
-    for (uint32_t i = lo; i < hi; i++) sum += row[i];
-    s_part[c][j] = sum;
-    __syncthreads();
-    for (uint32_t d = 1; d < 128u; d <<= 1) {
-        const uint32_t add = j >= d ? s_part[c][j - d] : 0u;
-        __syncthreads();
-        s_part[c][j] += add;
-        __syncthreads();
+    uint32_t run = 0;
+    for (uint32_t i0 = 0; i0 < n_waves; i0 += 512u) {  // eight steps' loads in flight together (a step alone is one load latency)
+        uint32_t v0, v1, v2, v3, v4, v5, v6, v7;
+#define RT_SCAN_LD(k) v##k = i0 + (k) * 64u + lane < n_waves ? row[i0 + (k) * 64u + lane] : 0u;
+        RT_SCAN_LD(0) RT_SCAN_LD(1) RT_SCAN_LD(2) RT_SCAN_LD(3) RT_SCAN_LD(4) RT_SCAN_LD(5) RT_SCAN_LD(6) RT_SCAN_LD(7)
+#undef RT_SCAN_LD
+#define RT_SCAN_STEP(k)                                                      \
+    {                                                                        \
+        uint32_t incl = v##k;                                                \
+        for (int d = 1; d < 64; d <<= 1) {                                   \
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);       \
+            if ((int)lane >= d) incl += up;                                  \
+        }                                                                    \
+        const uint32_t i = i0 + (k) * 64u + lane;                            \
+        if (i < n_waves) row[i] = run + incl - v##k;                         \
+        run += (uint32_t)__shfl((int)incl, 63, 64);                          \
     }
-    uint32_t run = j ? s_part[c][j - 1] : 0u;
-#pragma unroll 16
-    for (uint32_t i = lo; i < hi; i++) {
-        const uint32_t v = row[i];
-        row[i] = run;
-        run += v;
+        RT_SCAN_STEP(0) RT_SCAN_STEP(1) RT_SCAN_STEP(2) RT_SCAN_STEP(3) RT_SCAN_STEP(4) RT_SCAN_STEP(5) RT_SCAN_STEP(6) RT_SCAN_STEP(7)
+#undef RT_SCAN_STEP
     }
-    if (j == 127u) ctl->cls_count[it_abs & 3u][c][0] = s_part[c][127];
+    if (lane == 0) ctl->cls_count[it_abs & 3u][c][0] = run;
 }
 template <int DUMMY>
 __global__ __launch_bounds__(256) void k_classify_scatter(const uint32_t* __restrict__ queue, const uint32_t* __restrict__ hitw, PathState st,
@@ -1078,8 +1077,11 @@ RTD void rec_store_direct(const PathState& out, uint32_t os, const ShadeA& a, co
 // Persistent, barrier-free: a wave takes a contiguous span of the list in 64-entry groups; output slots, queue entries
 // (a chunk per ray kind, so a traversal wave's reservation is mostly one kind) and fold-list entries come from
 // per-wave chunks of the shared counters; records move as whole lines through the wave's staging area in LDS.
-template <int FEAT, int KIND>
-__global__ __launch_bounds__(256, RT_SHADE_BOUND(FEAT)) void k_shade_cls(DevScene sc, PathState in, PathState out, Ctl* ctl, uint32_t it_abs,
+// WAVES: waves per SIMD the instance is compiled for.  3 for the single-lobe instances (168 VGPRs, 35-110 of them spilled)
+// -- except that a scene whose classes are ALL Lambertian runs <0, KIND, 2>: no spills, and C2's two classes gain 12 %
+// where C4's Lambertian floor loses 4 % (profiles/r04_exp_feat0_waves.txt).
+template <int FEAT, int KIND, int WAVES = RT_SHADE_BOUND(FEAT)>
+__global__ __launch_bounds__(256, WAVES) void k_shade_cls(DevScene sc, PathState in, PathState out, Ctl* ctl, uint32_t it_abs,
                                                uint32_t max_depth, Lists lists, uint32_t cls, uint32_t* queue_out, uint32_t q_cap,
                                                uint32_t slot_cap, f64_t* lf, DevStats* stats) {
     const uint32_t itn = (it_abs + 1) % kRing;

@@ -31,6 +31,7 @@ typedef void (*TonemapKernel)(const double*, const uint32_t*, uint64_t, uint8_t*
 struct KernelTable {
     // [precision: 0 = binary64, 1 = binary32]
     ShadeClsKernel shade_cls[2][kVariants][3];  // [variant][kind: any / mesh / other]
+    ShadeClsKernel shade_cls_w2[2][3];          // the Lambert-only instance compiled for 2 waves/SIMD (all-Lambert scenes)
     ShadeLightKernel shade_light[2][2];         // [environment light]
     TailKernel tail[2][kVariants][2];           // [variant][counting]
     TraceKernel trace[2][3];                    // 0: simple scenes, 1: general, 2: counting

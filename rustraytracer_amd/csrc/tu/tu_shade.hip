@@ -17,6 +17,11 @@ struct Reg {
         t.shade_cls[P][V][rtc::kKindAny] = K::k_shade_cls<F, rtc::kKindAny>;
         t.shade_cls[P][V][rtc::kKindMesh] = K::k_shade_cls<F, rtc::kKindMesh>;
         t.shade_cls[P][V][rtc::kKindOther] = K::k_shade_cls<F, rtc::kKindOther>;
+#if RT_TU_V == 0
+        t.shade_cls_w2[P][rtc::kKindAny] = K::k_shade_cls<0, rtc::kKindAny, 2>;
+        t.shade_cls_w2[P][rtc::kKindMesh] = K::k_shade_cls<0, rtc::kKindMesh, 2>;
+        t.shade_cls_w2[P][rtc::kKindOther] = K::k_shade_cls<0, rtc::kKindOther, 2>;
+#endif
         t.tail[P][V][0] = K::k_tail<F, false>;
         t.tail[P][V][1] = K::k_tail<F, true>;
     }
