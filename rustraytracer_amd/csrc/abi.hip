@@ -61,6 +61,7 @@ struct Lane {
     hipStream_t stream = nullptr;
     uint32_t capacity = 0;
     void* pool = nullptr;
+    size_t pool_bytes = 0;
     uint32_t pool_cls = 0;  // class lists the pool was laid out for
     PathState st[2] = {};
     uint32_t* queue[2] = {nullptr, nullptr};
@@ -162,12 +163,13 @@ static uint32_t test_pool_oom_above() { return 0u; }
 static void pool_layout(uint32_t cap, uint32_t n_cls, size_t& slots, size_t& qn, size_t& bytes) {
     // every shading wave may leave the end of its last chunk of slots / queue entries / list entries unused: at most 1/16
     // of a launch's entries per kernel (kernels.hip: pick_chunk), summed generously
-    slots = (size_t)cap + cap / 8 + 65536;
+    slots = (size_t)cap + std::min<size_t>(cap / 16, (size_t)16 << 20) + 65536;
     qn = 3 * slots;
     // per slot and pool: the 256-B record + 12 ray words + 2 result words + the camera sample's RNG state; 2 fold lists;
     // per queue entry: 2 queues + hit words
     bytes = slots * (2 * ((size_t)kRecBytes + 12 * 8 + 2 * 4 + 8) + 2 * sizeof(uint32_t)) + 3 * qn * sizeof(uint32_t) +
-            (size_t)n_cls * slots * sizeof(ListEnt) + 4096;
+            slots * sizeof(ListEnt) + 4096;  // (the class lists share one arena: every path is in at most one of them)
+    (void)n_cls;
 }
 
 static int ensure_lane_capacity(rt_context* c, Lane& ln, uint32_t cap, uint32_t n_cls) {
@@ -183,6 +185,7 @@ static int ensure_lane_capacity(rt_context* c, Lane& ln, uint32_t cap, uint32_t 
     if (ln.pool) {
         HIP_TRY(hipFree(ln.pool));
         ln.pool = nullptr;
+        ln.pool_bytes = 0;
         ln.capacity = 0;
         ln.pool_cls = 0;
     }
@@ -192,6 +195,7 @@ static int ensure_lane_capacity(rt_context* c, Lane& ln, uint32_t cap, uint32_t 
     void* slab = nullptr;
     HIP_TRY(hipMalloc(&slab, bytes));  // (on failure ln.pool stays null and ln.capacity 0: the caller may retry smaller)
     ln.pool = slab;
+    ln.pool_bytes = bytes;
     char* p = (char*)ln.pool;
     for (int b = 0; b < 2; b++) {
         PathState& st = ln.st[b];
@@ -206,7 +210,7 @@ static int ensure_lane_capacity(rt_context* c, Lane& ln, uint32_t cap, uint32_t 
         st.sh_prim = (int32_t*)p; p += slots * 4;
         st.pr_prim = (int32_t*)p; p += slots * 4;
     }
-    ln.lists.ent = (ListEnt*)p; p += (size_t)n_cls * slots * sizeof(ListEnt);
+    ln.lists.ent = (ListEnt*)p; p += slots * sizeof(ListEnt);
     ln.queue[0] = (uint32_t*)p; p += qn * sizeof(uint32_t);
     ln.queue[1] = (uint32_t*)p; p += qn * sizeof(uint32_t);
     ln.hitw = (uint32_t*)p; p += qn * sizeof(uint32_t);
@@ -1246,10 +1250,12 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
             HIP_TRY(hipMalloc((void**)&c->lf, batch_cap * 3 * sizeof(double)));
             c->lf_capacity = batch_cap;
         }
-        // default pool: 256 Mi paths = a whole batch (140 GB of path state of the 288 GB when a batch is that large; smaller
+        // default pool: 256 Mi paths = a whole batch (0.8 KB per path: 225 GB of the 288 GB when a batch is that large; smaller
         // batches size it down).  Fewer, fuller launches: C4 3822 / 4077 / 4105 / 4206 Mrays/s at 16 / 64 / 128 / 256 Mi,
-        // C3 3910 / 4090 / 4141 / 4185 (profiles/r03_sweep_pool.txt, r03_sweep_pool_big.txt).  A default that does not fit
-        // the memory that is free is halved (down to 16 Mi) instead of failing; a size the caller asked for is not.
+        // C3 3910 / 4090 / 4141 / 4185 (profiles/r03_sweep_pool.txt, r03_sweep_pool_big.txt).  A default that does not leave
+        // kPoolHeadroom of the device's free memory to everybody else (the next scene commit, the fast mode's leaf copies, the
+        // caller's own buffers, other ranks sharing the GPU), or that fails to allocate, is halved (down to 16 Mi) instead of
+        // failing; a size the caller asked for is not.
         const bool pool_default = cfg->paths_in_flight == 0;
         uint32_t P = pool_default ? (1u << 28) : cfg->paths_in_flight;
         P = std::max<uint32_t>(64u, std::min<uint32_t>(P, 1u << 28));
@@ -1259,9 +1265,20 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
             n_lanes = (batch_cap > (size_t)P) ? c->n_lanes : 1;
             P = (uint32_t)std::min<size_t>(P, (batch_cap + 63) & ~(size_t)63);
             int rc = RT_OK;
+            const uint32_t floor_paths = test_pool_oom_above() ? 64u : (1u << 24);
+            if (pool_default && P > floor_paths && c->lanes[0].capacity < P) {
+                constexpr size_t kPoolHeadroom = (size_t)12 << 30;
+                size_t fr = 0, tot = 0, slots, qn, bytes;
+                pool_layout(P, s->n_cls, slots, qn, bytes);
+                size_t held = 0;  // (a smaller pool of an earlier render is released first)
+                for (int i = 0; i < n_lanes; i++) held += c->lanes[i].pool_bytes;
+                if (hipMemGetInfo(&fr, &tot) == hipSuccess && bytes * (size_t)n_lanes + kPoolHeadroom > fr + held) {
+                    P >>= 1;
+                    continue;
+                }
+            }
             for (int i = 0; i < n_lanes && rc == RT_OK; i++) rc = ensure_lane_capacity(c, c->lanes[i], P, s->n_cls);
             if (rc == RT_OK) break;
-            const uint32_t floor_paths = test_pool_oom_above() ? 64u : (1u << 24);
             if (rc != RT_ERR_OOM || !pool_default || P <= floor_paths) return rc;
             (void)hipGetLastError();
             P >>= 1;

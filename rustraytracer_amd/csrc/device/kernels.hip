@@ -662,6 +662,7 @@ __global__ __launch_bounds__(256) void k_classify_count(const uint32_t* __restri
 template <int DUMMY>
 __global__ __launch_bounds__(512) void k_classify_scan(uint32_t* counts, uint32_t n_waves, Ctl* ctl, uint32_t it_abs) {
     static_assert(kMaxCls == 8, "one wave per class");
+    __shared__ uint32_t s_total[kMaxCls];
     const uint32_t c = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint32_t* row = counts + c * n_waves;
     uint32_t run = 0;
@@ -684,7 +685,16 @@ __global__ __launch_bounds__(512) void k_classify_scan(uint32_t* counts, uint32_
         RT_SCAN_STEP(0) RT_SCAN_STEP(1) RT_SCAN_STEP(2) RT_SCAN_STEP(3) RT_SCAN_STEP(4) RT_SCAN_STEP(5) RT_SCAN_STEP(6) RT_SCAN_STEP(7)
 #undef RT_SCAN_STEP
     }
-    if (lane == 0) ctl->cls_count[it_abs & 3u][c][0] = run;
+    if (lane == 0) {
+        ctl->cls_count[it_abs & 3u][c][0] = run;
+        s_total[c] = run;
+    }
+    __syncthreads();
+    if (lane == 0) {  // the lists share one arena, back to back in class order
+        uint32_t base = 0;
+        for (uint32_t k = 0; k < c; k++) base += s_total[k];
+        ctl->cls_base[it_abs & 3u][c] = base;
+    }
 }
 template <int DUMMY>
 __global__ __launch_bounds__(256) void k_classify_scatter(const uint32_t* __restrict__ queue, const uint32_t* __restrict__ hitw, PathState st,
@@ -697,7 +707,8 @@ __global__ __launch_bounds__(256) void k_classify_scatter(const uint32_t* __rest
     if (g_first >= g_end) return;
     uint32_t at[kMaxCls];
 #pragma unroll
-    for (int c = 0; c < kMaxCls; c++) at[c] = (uint32_t)c < lists.n_cls ? offsets[(uint32_t)c * n_waves + wave_g] : 0u;
+    for (int c = 0; c < kMaxCls; c++)
+        at[c] = (uint32_t)c < lists.n_cls ? ctl->cls_base[it_abs & 3u][c] + offsets[(uint32_t)c * n_waves + wave_g] : 0u;
     // the camera samples k_generate appended to this queue: entries [gen_q, gen_q + gen_count), sample gen_first + k
     const uint32_t fresh_lo = ctl->gen_q, fresh_n = ctl->gen_count, fresh_g = ctl->gen_first;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -732,7 +743,7 @@ __global__ __launch_bounds__(256) void k_classify_scatter(const uint32_t* __rest
                 const bool mine = cls == (uint32_t)c;
                 const unsigned long long m = __ballot(mine);
                 const uint32_t to = at[c] + (uint32_t)__popcll(m & below);
-                if (mine && to < lists.cap) lists.ent[(size_t)c * lists.cap + to] = ListEnt{slot_word, hw, w2, pr4[u]};
+                if (mine && to < lists.cap) lists.ent[to] = ListEnt{slot_word, hw, w2, pr4[u]};
                 at[c] += (uint32_t)__popcll(m);
             }
         }
@@ -1095,7 +1106,7 @@ __global__ __launch_bounds__(256, WAVES) void k_shade_cls(DevScene sc, PathState
     const uint32_t g_first = wave_g * per_wave, g_end = g_first + per_wave < n_groups ? g_first + per_wave : n_groups;
     if (g_first >= g_end) return;
     const uint32_t chunk = pick_chunk(n, n_waves < n_groups ? n_waves : n_groups);
-    const ListEnt* ent = lists.ent + (size_t)cls * lists.cap;
+    const ListEnt* ent = lists.ent + ctl->cls_base[it_abs & 3u][cls];
     uint32_t* fold_out = lists.fold[(it_abs + 1u) & 1u];
     uint32_t* const c_slots = &ctl->n_active[itn];
     uint32_t* const c_rays = &ctl->n_rays[itn];

@@ -176,9 +176,9 @@ struct alignas(16) ListEnt {
     int32_t sh, pr;      // the shadow / probe ray's result (meaningful with kEntPending)
 };
 struct Lists {
-    ListEnt* ent;      // [n_cls][cap]: {slot, hit word}; class c at ent + c * cap
+    ListEnt* ent;      // one arena of `cap` entries: the lists of an iteration back to back, class c from Ctl::cls_base[..][c]
     uint32_t* fold[2];  // slots of fold-only paths, written by the shading kernels of iteration it for it + 1
-    uint32_t cap;      // entries per list
+    uint32_t cap;      // entries in the arena / in a fold list
     uint32_t n_cls;
 };
 
@@ -202,6 +202,7 @@ struct Ctl {
     uint32_t xhead[4][8][32];
     // lengths of the class lists / the fold list of an iteration (ring of 4), each counter on its own 128-B line
     uint32_t cls_count[4][kMaxCls][32];
+    uint32_t cls_base[4][kMaxCls];  // where the list of a class starts in Lists::ent (k_classify_scan)
     uint32_t fold_count[4][32];
 };
 
