@@ -228,9 +228,11 @@ typedef struct rt_render_cfg {
     uint32_t tile_world;      /*   rt_tile_owner(tx, ty, tile_world) ==
                                    tile_rank (below); 0 = 1                    */
     uint32_t precision;       /* rt_precision                                  */
-    uint32_t paths_in_flight; /* path-state slots kept alive per device (520 B
-                                   each); 0 = library default: a whole batch, at
-                                   most 2^28 (140 GB), halved until it fits      */
+    uint32_t paths_in_flight; /* path-state slots kept alive per device (about
+                                   0.8 KB each); 0 = library default: a whole
+                                   batch, at most 2^28 (225 GB), halved until it
+                                   fits and leaves 12 GB of the device's free
+                                   memory to everybody else                      */
     uint32_t flags;           /* RT_RENDER_* below                             */
     /* Progressive passes (next-row f4; render.rs:161-324 refines the picture while
      * it is displayed): this call renders samples [sample_first, sample_first +
