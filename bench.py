@@ -65,7 +65,8 @@ WORKLOADS = {
 
 # Algorithmic bytes of the shading kernels (round-4 layout):
 #   per path entering a bounce (= extension ray, R1): its 16-B list entry; line 0 of its record (128 B) unless it is a
-#     camera sample, which has no record yet;
+#     camera sample, which has no record yet -- in the class kernel of its vertex, or in the light kernel when the ray
+#     found nothing (light_bytes);
 #   per shaded vertex: line 0 of the survivor's record written (128 B), its ray written to the ray arrays (48 B), the
 #     winner's scene records (72 B vertices + 72 B normals + 8 B meta + 120 B primitive or material record: SURVEY.md
 #     8d's B_shade doubled for f64 = 272 B);
@@ -76,9 +77,20 @@ CLASSIFY_BYTES_PER_RAY = 2 * 8 + 16  # queue entry + hit word read by the count 
 
 
 def shade_bytes(st):
+    """The class kernels (vertices) -- the paths that end without a vertex are light_bytes()."""
     pending = max(st.rays_shadow, st.rays_probe)
-    return (16 * st.rays_extension + 128 * max(st.rays_extension - st.paths, 0) + SHADE_BYTES_PER_VERTEX * st.vertices_shaded +
+    hits = min(st.vertices_shaded, st.rays_extension)
+    stored = max(st.rays_extension - st.paths, 0) * hits // max(st.rays_extension, 1)  # (hits that are not camera samples)
+    return (16 * hits + 128 * stored + SHADE_BYTES_PER_VERTEX * st.vertices_shaded +
             256 * pending + 24 * (st.rays_shadow + st.rays_probe))
+
+
+def light_bytes(st):
+    """The light kernel: per extension ray that found nothing its 16-B list entry, line 0 of its record (128 B) unless it
+    is a camera sample, and the 24 B of film staging it retires into."""
+    esc = max(st.rays_extension - st.vertices_shaded, 0)
+    stored = max(st.rays_extension - st.paths, 0) * esc // max(st.rays_extension, 1)
+    return (16 + 24) * esc + 128 * stored
 
 
 def pick_roofline(kernels):
@@ -280,7 +292,7 @@ def timed(b, steps, warmup, barrier):
     barrier()
     b.gather_s = 0.0
     acc = {"rays": 0, "trace_ms": 0.0, "kernel_ms": 0.0, "launches": 0, "shade_ms": 0.0, "shade_launches": 0,
-           "vertices": 0, "classify_ms": 0.0, "r1": 0, "r2": 0, "r3": 0}
+           "vertices": 0, "classify_ms": 0.0, "light_ms": 0.0, "r1": 0, "r2": 0, "r3": 0}
     t0 = time.perf_counter()
     for _ in range(steps):
         st = b.step()
@@ -291,6 +303,7 @@ def timed(b, steps, warmup, barrier):
         acc["shade_ms"] += st.shade_ms
         acc["shade_launches"] += st.shade_launches
         acc["classify_ms"] += st.classify_ms
+        acc["light_ms"] += st.light_ms
         acc["r1"] += st.rays_extension
         acc["r2"] += st.rays_shadow
         acc["r3"] += st.rays_probe
@@ -302,11 +315,12 @@ def timed(b, steps, warmup, barrier):
 
 def pmc_groups(rec):
     """Per kernel group, the HBM bytes per step of a committed counter profile (profiles/trace_pmc_<workload>.json:
-    per_kernel_hbm_read_bytes_per_step / ..write..): k_trace = the timed instance, k_shade = class kernels + light
-    kernel, k_classify = the three launches of the counting sort."""
+    per_kernel_hbm_read_bytes_per_step / ..write..): k_trace = the timed instance, k_shade = the class kernels,
+    k_shade_light = the light kernel, k_classify = the three launches of the counting sort."""
     rd, wr = rec.get("per_kernel_hbm_read_bytes_per_step") or {}, rec.get("per_kernel_hbm_write_bytes_per_step") or {}
     out = {}
-    for grp, needles in (("k_trace", ("k_trace<false",)), ("k_shade", ("k_shade_cls", "k_shade_light")), ("k_classify", ("k_classify_",))):
+    for grp, needles in (("k_trace", ("k_trace<false",)), ("k_shade", ("k_shade_cls",)), ("k_shade_light", ("k_shade_light",)),
+                         ("k_classify", ("k_classify_",))):
         r = sum(v for k, v in rd.items() if any(n in k for n in needles))
         w = sum(v for k, v in wr.items() if any(n in k for n in needles))
         if r or w:
@@ -326,16 +340,19 @@ def roofline(b, acc, stc, steps):
         "k_trace": {"ms_per_step": acc["trace_ms"] / steps, "algorithmic_bytes_per_step": alg},
         "k_shade": {"ms_per_step": acc["shade_ms"] / steps, "algorithmic_bytes_per_step": shade_bytes(stc),
                     "kernels_per_bounce": b.info.get("n_classes"),
-                    "note": "one kernel per vertex class of the scene + one for escaped / fold-only paths; f64 VALU issue "
-                            "and latency share the bound with bytes (DESIGN.md section 4)"},
+                    "note": "one kernel per vertex class of the scene; f64 VALU issue and latency share the bound with "
+                            "bytes (DESIGN.md section 4)"},
         "k_classify": {"ms_per_step": acc["classify_ms"] / steps, "algorithmic_bytes_per_step": CLASSIFY_BYTES_PER_RAY * stc.rays},
+        # the kernel for escaped / fold-only paths runs on a side stream BESIDE the class kernels and the next k_trace launch:
+        # its time (HIP events on that stream) overlaps theirs, and its rate is what it gets next to them, not alone
+        "k_shade_light": {"ms_per_step": acc["light_ms"] / steps, "algorithmic_bytes_per_step": light_bytes(stc), "overlapped": True},
     }
     for g in groups.values():
         s = g["ms_per_step"] / 1e3
         g["bound"], g["peak"], g["unit"] = "hbm", HBM_PEAK_GBS, "GB/s"
         g["achieved"] = g["algorithmic_bytes_per_step"] / s / 1e9 if s > 0 else 0.0
         g["frac_algorithmic"] = g["achieved"] / HBM_PEAK_GBS
-        g["share_of_device_time"] = g["ms_per_step"] * steps / dev_ms
+        g["share_of_device_time"] = None if g.get("overlapped") else g["ms_per_step"] * steps / dev_ms
         g["hbm_frac_rocprof"] = g["hbm_read_frac_rocprof"] = g["traffic_per_step"] = None
     # Counter figures come from a committed rocprofv3 --pmc profile (counters cannot be read inside this run); the
     # profile names the kernel build it was taken from, and the figures are WITHHELD (null, with the reason in

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 4  /* 4 (round 4): rt_stats.classify_ms, rt_scene_info.n_classes appended */
+#define RT_ABI_VERSION 5  /* 4 (round 4): rt_stats.classify_ms, rt_scene_info.n_classes appended; 5: rt_stats.light_ms */
 
 /* ---------------------------------------------------------------- status */
 typedef enum rt_status {
@@ -304,11 +304,15 @@ typedef struct rt_stats {
      * time), gather_ms is the host-clock time of the final peer-to-peer film gather.                   */
     double gather_ms;
     uint64_t n_devices;
-    double shade_ms;           /* shading kernels only (HIP events), like trace_ms: per bounce one kernel
-                                  per vertex class of the scene + the one for escaped / fold-only paths */
+    double shade_ms;           /* the class kernels only (HIP events), like trace_ms: per bounce one kernel
+                                  per vertex class of the scene; the light kernel is in light_ms        */
     uint64_t shade_launches;   /* bounces shaded (not kernels)                 */
     double classify_ms;        /* (ABI 4) the counting sort that deals the traced paths to the lists of
                                   their vertex classes, between the two (HIP events)                  */
+    double light_ms;           /* (ABI 5) the kernel for escaped / fold-only paths (HIP events on its own
+                                  stream).  It runs BESIDE the class kernels and the next traversal
+                                  launch, so this time overlaps trace_ms / shade_ms: the four do not add
+                                  up to kernel_ms                                                      */
 } rt_stats;
 
 typedef struct rt_ray {

@@ -111,7 +111,7 @@ class rt_stats(C.Structure):
         ("tail_rays", C.c_uint64), ("tail_nodes_fetched", C.c_uint64), ("tail_tris_tested", C.c_uint64),
         ("tail_others_tested", C.c_uint64),
         ("gather_ms", C.c_double), ("n_devices", C.c_uint64),
-        ("shade_ms", C.c_double), ("shade_launches", C.c_uint64), ("classify_ms", C.c_double),
+        ("shade_ms", C.c_double), ("shade_launches", C.c_uint64), ("classify_ms", C.c_double), ("light_ms", C.c_double),
     ]
 
     def as_dict(self):

@@ -76,8 +76,12 @@ struct Lane {
     uint32_t seq = 1;  // next mirror sequence number (unique per iteration ever launched on this lane)
     std::vector<hipEvent_t> events;
     size_t ev_i = 0;
+    // the light kernel's own stream (run_lane) and the events that order it against the lane's stream (no timing)
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> sync_events;
+    size_t sync_i = 0;
     // per-render results of this lane
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_ev, classify_ev, shade_ev;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_ev, classify_ev, shade_ev, light_ev;
     uint64_t trace_launches = 0, shade_launches = 0;
     int rc = RT_OK;
     char err[512] = "";
@@ -304,6 +308,7 @@ static int context_init(rt_context* c) {
     for (int i = 0; i < kLanes; i++) {
         Lane& ln = c->lanes[i];
         HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&ln.side, hipStreamNonBlocking));
         HIP_TRY(hipHostMalloc((void**)&ln.mirror_h, sizeof(MirrorEntry) * kRing, hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(ln.mirror_h, 0, sizeof(MirrorEntry) * kRing);
         HIP_TRY(hipHostGetDevicePointer((void**)&ln.mirror_d, ln.mirror_h, 0));
@@ -329,6 +334,8 @@ int rt_context_destroy(rt_context* c) {
     for (int i = 0; i < kLanes; i++) {
         Lane& ln = c->lanes[i];
         for (auto ev : ln.events) (void)hipEventDestroy(ev);
+        for (auto ev : ln.sync_events) (void)hipEventDestroy(ev);
+        if (ln.side) (void)hipStreamDestroy(ln.side);
         if (ln.pool) (void)hipFree(ln.pool);
         if (ln.ctl) (void)hipFree(ln.ctl);
         if (ln.cls_tab) (void)hipFree(ln.cls_tab);
@@ -945,10 +952,10 @@ static uint32_t next_pow2(uint32_t v) {  // sampler.rs:633-642
     return p;
 }
 
-static hipEvent_t get_event(std::vector<hipEvent_t>& pool, size_t i) {
+static hipEvent_t get_event(std::vector<hipEvent_t>& pool, size_t i, bool timing = true) {
     while (pool.size() <= i) {
         hipEvent_t ev;
-        if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+        if ((timing ? hipEventCreate(&ev) : hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return nullptr;
         pool.push_back(ev);
     }
     return pool[i];
@@ -965,6 +972,7 @@ struct RenderJob {
     std::atomic<bool> abort{false};
     std::atomic<bool> cancelled{false};  // rt_render_cfg.cancel was seen non-zero
     int trace_blocks;
+    bool light_overlap = false;  // the light kernel runs on the lane's side stream, under the next traversal launch
     int shade_blocks[kMaxCls];  // resident blocks of each class kernel (persistent grids); [0]: the light kernel
     bool count_trav;
     bool f32;  // RT_PRECISION_F32: the binary32 kernel set
@@ -1014,6 +1022,17 @@ static int run_lane(RenderJob& job, int lane_id) {
     LANE_TRY(hipSetDevice(c->device));
     static const bool no_ev = getenv("RT_NO_TRACE_EVENTS") != nullptr;
     hipStream_t stream = ln.stream;
+    // The light kernel of iteration `it` needs the lists of `it` and writes film staging only: with job.light_overlap it
+    // runs on the side stream from the end of k_classify_scatter(it) on, beside the class kernels of `it` and k_trace(it+1)
+    // (memory-bound, a tenth of the VALU busy, under two issue-bound kernels), and has to be through before the next
+    // scatter overwrites the lists -- and before anything else that touches both pools (k_tail) or ends the lane.
+    hipEvent_t light_done = nullptr;
+    auto join_light = [&]() -> hipError_t {
+        if (!light_done) return hipSuccess;
+        const hipError_t e = hipStreamWaitEvent(stream, light_done, 0);
+        light_done = nullptr;
+        return e;
+    };
     const uint32_t P = job.pool;
     const uint32_t gen_blocks = (P + 255) / 256;
     LANE_TRY(hipMemsetAsync(ln.ctl, 0, sizeof(Ctl), stream));
@@ -1081,7 +1100,8 @@ static int run_lane(RenderJob& job, int lane_id) {
                 if (live <= c->tail_paths) {
                     // few paths left: one fused launch finishes them (k_tail) instead of ~2 launches per bounce
                     // that are each as slow as their single longest ray
-                                        const uint32_t tail_blocks = std::min((live + 255) / 256, (uint32_t)c->num_cus * 2u);  // persistent waves
+                    LANE_TRY(join_light());
+                    const uint32_t tail_blocks = std::min((live + 255) / 256, (uint32_t)c->num_cus * 2u);  // persistent waves
                     hipLaunchKernelGGL(tail_kernel(job.s->shade_variant, job.count_trav, job.f32_tail), dim3(tail_blocks), dim3(256), 0, stream, job.s->dev, ln.st[0],
                                        ln.st[1], ln.ctl, (uint32_t)it, cfg->max_depth, ln.queue[it & 1], ln.lists, c->lf, c->stats);
                     break;
@@ -1121,6 +1141,7 @@ static int run_lane(RenderJob& job, int lane_id) {
             hipLaunchKernelGGL(rtk::kernel_table().classify_count, dim3(cblocks), dim3(256), 0, stream, ln.queue[it & 1], ln.hitw, ln.ctl,
                                (uint32_t)it, ln.cls_tab);
             hipLaunchKernelGGL(rtk::kernel_table().classify_scan, dim3(1), dim3(512), 0, stream, ln.cls_tab, cblocks * 4u, ln.ctl, (uint32_t)it);
+            LANE_TRY(join_light());  // (the light kernel of the previous iteration still reads the lists)
             hipLaunchKernelGGL(rtk::kernel_table().classify_scatter, dim3(cblocks), dim3(256), 0, stream, ln.queue[it & 1], ln.hitw, ln.st[it & 1],
                                ln.ctl, (uint32_t)it, ln.cls_tab, ln.lists);
         }
@@ -1134,15 +1155,45 @@ static int run_lane(RenderJob& job, int lane_id) {
             LANE_TRY(hipEventRecord(b2, stream));
             ln.classify_ev.emplace_back(b, b2);
         }
-        // one kernel per vertex class, the heaviest instances first; then the paths that end without a vertex (escaped,
-        // fold only).  Persistent grids: a class with few paths this bounce costs a launch, not a grid of empty blocks.
+        // the paths that end without a vertex (escaped, fold only): the light kernel -- on the side stream when overlapped
+        auto launch_light = [&](hipStream_t on) -> int {
+            hipEvent_t l0 = nullptr, l1 = nullptr;
+            if (!no_ev) {
+                l0 = get_event(ln.events, ln.ev_i++);
+                l1 = get_event(ln.events, ln.ev_i++);
+                if (!l0 || !l1) {
+                    job.abort.store(true);
+                    return lane_fail(ln, RT_ERR_HIP, "hipEventCreate failed");
+                }
+                LANE_TRY(hipEventRecord(l0, on));
+            }
+            hipLaunchKernelGGL(shade_light_kernel(job.s->dev.env.light >= 0, job.f32_shade), dim3(std::min(shade_want, (uint32_t)job.shade_blocks[0])), dim3(256),
+                               0, on, job.s->dev, ln.st[it & 1], ln.ctl, (uint32_t)it, cfg->max_depth, ln.lists, c->lf);
+            if (!no_ev) {
+                LANE_TRY(hipEventRecord(l1, on));
+                ln.light_ev.emplace_back(l0, l1);
+            }
+            return RT_OK;
+        };
+        if (job.light_overlap) {
+            hipEvent_t lists_ready = get_event(ln.sync_events, ln.sync_i++, false);
+            light_done = get_event(ln.sync_events, ln.sync_i++, false);
+            if (!lists_ready || !light_done) {
+                job.abort.store(true);
+                return lane_fail(ln, RT_ERR_HIP, "hipEventCreate failed");
+            }
+            LANE_TRY(hipEventRecord(lists_ready, stream));
+            LANE_TRY(hipStreamWaitEvent(ln.side, lists_ready, 0));
+            if (int rc = launch_light(ln.side)) return rc;
+            LANE_TRY(hipEventRecord(light_done, ln.side));
+        }
+        // one kernel per vertex class, the heaviest instances first.  Persistent grids: a class with few paths this bounce
+        // costs a launch, not a grid of empty blocks.
         for (uint32_t k = 1; k < job.s->n_cls; k++)
             hipLaunchKernelGGL(shade_cls_kernel(job.s->cls[k], job.f32_shade, job.s->all_lambert), dim3(std::min(shade_want, (uint32_t)job.shade_blocks[k])), dim3(256), 0,
                                stream, job.s->dev, ln.st[it & 1], ln.st[(it + 1) & 1], ln.ctl, (uint32_t)it, cfg->max_depth, ln.lists, k,
                                ln.queue[(it + 1) & 1], ln.q_cap, ln.slot_cap, c->lf, c->stats);
-        hipLaunchKernelGGL(shade_light_kernel(job.s->dev.env.light >= 0, job.f32_shade), dim3(std::min(shade_want, (uint32_t)job.shade_blocks[0])), dim3(256),
-                           0, stream, job.s->dev, ln.st[it & 1], ln.ctl, (uint32_t)it, cfg->max_depth, ln.lists, c->lf);
-        if (!no_ev) {  // the shading kernel runs from event b (end of k_trace) to this one
+        if (!no_ev) {  // the class kernels run from event b2 (end of the classify launches) to this one
             hipEvent_t e = get_event(ln.events, ln.ev_i++);
             if (!e) {
                 job.abort.store(true);
@@ -1151,12 +1202,15 @@ static int run_lane(RenderJob& job, int lane_id) {
             LANE_TRY(hipEventRecord(e, stream));
             ln.shade_ev.emplace_back(b2, e);
         }
+        if (!job.light_overlap)
+            if (int rc = launch_light(stream)) return rc;
         ln.shade_launches++;
     }
     if (it >= max_iters) {
         job.abort.store(true);
         return lane_fail(ln, RT_ERR_HIP, "lane %d did not drain within %llu iterations", lane_id, max_iters);
     }
+    LANE_TRY(join_light());
     LANE_TRY(hipGetLastError());
     LANE_TRY(hipStreamSynchronize(stream));
     return RT_OK;
@@ -1224,7 +1278,7 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
         // (pix is a local: the copy has to finish before it goes out of scope on the early-return paths)
         HIP_TRY(hipMemcpyAsync(c->pix_list, c->last_pix.data(), NP * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     }
-    double kernel_ms = 0.0, trace_ms = 0.0, shade_ms = 0.0, classify_ms = 0.0;
+    double kernel_ms = 0.0, trace_ms = 0.0, shade_ms = 0.0, classify_ms = 0.0, light_ms = 0.0;
     uint64_t trace_launches = 0, shade_launches = 0;
     if (NP > 0 && pass_spp > 0) {
         // batch shape: PB pixels x ns samples, at most kBatchMax camera samples (film staging size)
@@ -1306,6 +1360,11 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
         int occ = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, trace_kernel(job.count_trav, s->dev.simple_others != 0, job.f32), 256, 0));
         int per_cu = std::max(1, occ);
+        // the light kernel beside the class kernels and the next traversal launch, one block per CU (128 VGPRs: a class
+        // kernel wave or a traversal block fewer on that SIMD while it is there): C4 4624 -> 4692 Mrays/s, C3 4226 -> 4395,
+        // C2 3809 -> 3929; with its full grid it only swaps places with the class kernels (profiles/r04_exp_light_overlap.txt)
+        job.light_overlap = true;
+        if (const char* e = getenv("RT_LIGHT_OVERLAP")) job.light_overlap = atoi(e) != 0;
         if (const char* e = getenv("RT_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));
         job.trace_blocks = c->num_cus * per_cu;
         for (uint32_t k = 0; k < s->n_cls; k++) {
@@ -1315,6 +1374,10 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
             else
                 HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&so, shade_cls_kernel(s->cls[k], job.f32, s->all_lambert), 256, 0));
             job.shade_blocks[k] = c->num_cus * std::max(1, so);
+            if (k == 0) {
+                if (job.light_overlap) job.shade_blocks[0] = c->num_cus;
+                if (const char* e = getenv("RT_LIGHT_BLOCKS_PER_CU")) job.shade_blocks[0] = c->num_cus * std::max(1, atoi(e));
+            }
         }
         size_t ev_i = 0;
         hipEvent_t ev_begin = get_event(c->events, ev_i++), ev_end = get_event(c->events, ev_i++);
@@ -1324,9 +1387,11 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
         for (int i = 0; i < n_lanes; i++) {
             Lane& ln = c->lanes[i];
             ln.ev_i = 0;
+            ln.sync_i = 0;
             ln.trace_ev.clear();
             ln.classify_ev.clear();
             ln.shade_ev.clear();
+            ln.light_ev.clear();
             ln.trace_launches = 0;
             ln.shade_launches = 0;
         }
@@ -1392,6 +1457,10 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
                 HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
                 classify_ms += ms;
             }
+            for (auto& pr : ln.light_ev) {
+                HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+                light_ms += ms;
+            }
             trace_launches += ln.trace_launches;
             shade_launches += ln.shade_launches;
         }
@@ -1426,6 +1495,7 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
         stats->shade_ms = shade_ms;
         stats->shade_launches = shade_launches;
         stats->classify_ms = classify_ms;
+        stats->light_ms = light_ms;
         if (getenv("RT_DIAG")) {
             unsigned long long d[4] = {0, 0, 0, 0}, over64 = 0, over256 = 0;
             for (int i = 0; i < kStatShards; i++) {
@@ -1587,7 +1657,7 @@ static int render_multi(rt_context* c, rt_scene* s, const rt_camera* cam, const 
             t.nodes_fetched += st[i].nodes_fetched; t.tris_tested += st[i].tris_tested;
             t.others_tested += st[i].others_tested; t.trace_ms += st[i].trace_ms;
             t.trace_launches += st[i].trace_launches; t.tail_rays += st[i].tail_rays;
-            t.shade_ms += st[i].shade_ms; t.shade_launches += st[i].shade_launches; t.classify_ms += st[i].classify_ms;
+            t.shade_ms += st[i].shade_ms; t.shade_launches += st[i].shade_launches; t.classify_ms += st[i].classify_ms; t.light_ms += st[i].light_ms;
             t.tail_nodes_fetched += st[i].tail_nodes_fetched; t.tail_tris_tested += st[i].tail_tris_tested;
             t.tail_others_tested += st[i].tail_others_tested;
             t.kernel_ms = std::max(t.kernel_ms, st[i].kernel_ms);  // the devices run side by side

@@ -73,7 +73,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(F.ABI_SYMBOLS) | set(F.HOST_SYMBOLS), declared ^ (set(F.ABI_SYMBOLS) | set(F.HOST_SYMBOLS))
     for name in sorted(declared):
         assert hasattr(L, name), name
-    assert L.rt_abi_version() == 4
+    assert L.rt_abi_version() == 5
     # the shared object really contains gfx950 code
     blob = open(F.LIB_PATH, "rb").read()
     assert b"amdgcn-amd-amdhsa--gfx950" in blob
@@ -102,7 +102,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(F.rt_camera) == 15 * 8 + 9 * 8
     assert C.sizeof(F.rt_ray) == 64 and C.sizeof(F.rt_hit) == 16
     assert C.sizeof(F.rt_render_cfg) == 80
-    assert C.sizeof(F.rt_stats) == 8 * 8 + 16 + 8 + 32 + 16 + 16 + 8
+    assert C.sizeof(F.rt_stats) == 8 * 8 + 16 + 8 + 32 + 16 + 16 + 8 + 8
 
 
 def test_error_behaviour_without_compute():
