@@ -191,6 +191,33 @@ def test_tail_launch_share_of_the_counters(gpu_ctx):
     gs.close()
 
 
+@pytest.mark.parametrize("name", ["two_dragons", "cornell_box_statue", "hdr"])
+def test_light_kernel_on_the_side_stream_changes_nothing(gpu_ctx, monkeypatch, name):
+    """run_lane: the kernel for escaped / fold-only paths runs on the lane's side stream, beside the class kernels and
+    the next traversal launch (default), ordered by events against the scatter that rewrites its lists, the fused tail
+    and the end of the lane.  Same film, counts and counters as the serial schedule (RT_LIGHT_OVERLAP=0), with small pools
+    (many iterations, the lists rewritten every time) and the default one; rt_stats.light_ms is reported in both."""
+    if name == "two_dragons":
+        sc = rr.two_dragons(mesh_faces=30000)
+    elif name == "hdr":
+        sc = rr.material_hdr(0, mesh_faces=12000)
+    else:
+        sc = rr.cornell_box_statue(mesh_faces=30000, variant=0)
+    gs = gpu_ctx.upload(sc)
+    for pool in (0, 4096, 70000):
+        cfg = rr.make_cfg(160, 120, 16, seed=5, paths_in_flight=pool)
+        monkeypatch.setenv("RT_LIGHT_OVERLAP", "0")
+        r0, n0, s0 = gpu_ctx.render(gs, sc.camera, cfg)
+        monkeypatch.delenv("RT_LIGHT_OVERLAP")
+        r1, n1, s1 = gpu_ctx.render(gs, sc.camera, cfg)
+        assert np.array_equal(r0, r1) and np.array_equal(n0, n1)
+        assert (s0.paths, s0.rays_extension, s0.rays_shadow, s0.rays_probe, s0.vertices_shaded) == \
+               (s1.paths, s1.rays_extension, s1.rays_shadow, s1.rays_probe, s1.vertices_shaded)
+        if s1.shade_launches:
+            assert s0.light_ms > 0.0 and s1.light_ms > 0.0
+    gs.close()
+
+
 def test_primitive_count_limit():
     L = F.lib()
     ctx = rr.Context(0)
