@@ -78,6 +78,7 @@ struct Lane {
     size_t ev_i = 0;
     // the light kernel's own stream (run_lane) and the events that order it against the lane's stream (no timing)
     hipStream_t side = nullptr;
+    hipStream_t cls_side[2] = {nullptr, nullptr};  // class kernels of one bounce side by side (run_lane: RT_CLS_STREAMS)
     std::vector<hipEvent_t> sync_events;
     size_t sync_i = 0;
     // per-render results of this lane
@@ -309,6 +310,7 @@ static int context_init(rt_context* c) {
         Lane& ln = c->lanes[i];
         HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&ln.side, hipStreamNonBlocking));
+        for (auto& cs : ln.cls_side) HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
         HIP_TRY(hipHostMalloc((void**)&ln.mirror_h, sizeof(MirrorEntry) * kRing, hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(ln.mirror_h, 0, sizeof(MirrorEntry) * kRing);
         HIP_TRY(hipHostGetDevicePointer((void**)&ln.mirror_d, ln.mirror_h, 0));
@@ -336,6 +338,7 @@ int rt_context_destroy(rt_context* c) {
         for (auto ev : ln.events) (void)hipEventDestroy(ev);
         for (auto ev : ln.sync_events) (void)hipEventDestroy(ev);
         if (ln.side) (void)hipStreamDestroy(ln.side);
+        for (auto cs : ln.cls_side) if (cs) (void)hipStreamDestroy(cs);
         if (ln.pool) (void)hipFree(ln.pool);
         if (ln.ctl) (void)hipFree(ln.ctl);
         if (ln.cls_tab) (void)hipFree(ln.cls_tab);
@@ -973,6 +976,7 @@ struct RenderJob {
     std::atomic<bool> cancelled{false};  // rt_render_cfg.cancel was seen non-zero
     int trace_blocks;
     bool light_overlap = false;  // the light kernel runs on the lane's side stream, under the next traversal launch
+    int cls_streams = 2;         // streams the class kernels of one bounce alternate between
     int shade_blocks[kMaxCls];  // resident blocks of each class kernel (persistent grids); [0]: the light kernel
     bool count_trav;
     bool f32;  // RT_PRECISION_F32: the binary32 kernel set
@@ -1189,10 +1193,36 @@ static int run_lane(RenderJob& job, int lane_id) {
         }
         // one kernel per vertex class, the heaviest instances first.  Persistent grids: a class with few paths this bounce
         // costs a launch, not a grid of empty blocks.
-        for (uint32_t k = 1; k < job.s->n_cls; k++)
+        // The class kernels of one bounce are independent of each other (shared cursors and counters are atomics): they
+        // alternate between the lane's stream and a second one, so that two of them are resident together -- a glass class
+        // that waits for its records beside a Lambert class that issues f64 arithmetic.  C4 4725 -> 4825 Mrays/s, C2 3940 ->
+        // 4020, hdr 2135 -> 2245, C3 (two classes of the same kind of work) +- 0; three streams: no better than one
+        // (profiles/r04_exp_class_streams.txt).  RT_CLS_STREAMS=1: one after the other.
+        const int cls_streams = job.cls_streams;
+        hipEvent_t cls_fork = nullptr;
+        bool cls_used[2] = {false, false};
+        if (cls_streams > 1 && job.s->n_cls > 2) {
+            cls_fork = get_event(ln.sync_events, ln.sync_i++, false);
+            LANE_TRY(hipEventRecord(cls_fork, stream));
+        }
+        for (uint32_t k = 1; k < job.s->n_cls; k++) {
+            hipStream_t on = stream;
+            const int w = cls_fork ? (int)((k - 1) % (uint32_t)cls_streams) : 0;
+            if (w > 0) {
+                on = ln.cls_side[w - 1];
+                if (!cls_used[w - 1]) LANE_TRY(hipStreamWaitEvent(on, cls_fork, 0));
+                cls_used[w - 1] = true;
+            }
             hipLaunchKernelGGL(shade_cls_kernel(job.s->cls[k], job.f32_shade, job.s->all_lambert), dim3(std::min(shade_want, (uint32_t)job.shade_blocks[k])), dim3(256), 0,
-                               stream, job.s->dev, ln.st[it & 1], ln.st[(it + 1) & 1], ln.ctl, (uint32_t)it, cfg->max_depth, ln.lists, k,
+                               on, job.s->dev, ln.st[it & 1], ln.st[(it + 1) & 1], ln.ctl, (uint32_t)it, cfg->max_depth, ln.lists, k,
                                ln.queue[(it + 1) & 1], ln.q_cap, ln.slot_cap, c->lf, c->stats);
+        }
+        for (int w = 0; w < 2; w++)
+            if (cls_used[w]) {
+                hipEvent_t j = get_event(ln.sync_events, ln.sync_i++, false);
+                LANE_TRY(hipEventRecord(j, ln.cls_side[w]));
+                LANE_TRY(hipStreamWaitEvent(stream, j, 0));
+            }
         if (!no_ev) {  // the class kernels run from event b2 (end of the classify launches) to this one
             hipEvent_t e = get_event(ln.events, ln.ev_i++);
             if (!e) {
@@ -1365,6 +1395,7 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
         // C2 3809 -> 3929; with its full grid it only swaps places with the class kernels (profiles/r04_exp_light_overlap.txt)
         job.light_overlap = true;
         if (const char* e = getenv("RT_LIGHT_OVERLAP")) job.light_overlap = atoi(e) != 0;
+        if (const char* e = getenv("RT_CLS_STREAMS")) job.cls_streams = std::min(3, std::max(1, atoi(e)));
         if (const char* e = getenv("RT_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));
         job.trace_blocks = c->num_cus * per_cu;
         for (uint32_t k = 0; k < s->n_cls; k++) {

@@ -195,7 +195,8 @@ def test_tail_launch_share_of_the_counters(gpu_ctx):
 def test_light_kernel_on_the_side_stream_changes_nothing(gpu_ctx, monkeypatch, name):
     """run_lane: the kernel for escaped / fold-only paths runs on the lane's side stream, beside the class kernels and
     the next traversal launch (default), ordered by events against the scatter that rewrites its lists, the fused tail
-    and the end of the lane.  Same film, counts and counters as the serial schedule (RT_LIGHT_OVERLAP=0), with small pools
+    and the end of the lane; the class kernels of a bounce alternate between two streams and are joined before the next
+    bounce is planned.  Same film, counts and counters as the serial schedule (RT_LIGHT_OVERLAP=0), with small pools
     (many iterations, the lists rewritten every time) and the default one; rt_stats.light_ms is reported in both."""
     if name == "two_dragons":
         sc = rr.two_dragons(mesh_faces=30000)
@@ -207,8 +208,10 @@ def test_light_kernel_on_the_side_stream_changes_nothing(gpu_ctx, monkeypatch, n
     for pool in (0, 4096, 70000):
         cfg = rr.make_cfg(160, 120, 16, seed=5, paths_in_flight=pool)
         monkeypatch.setenv("RT_LIGHT_OVERLAP", "0")
+        monkeypatch.setenv("RT_CLS_STREAMS", "1")
         r0, n0, s0 = gpu_ctx.render(gs, sc.camera, cfg)
         monkeypatch.delenv("RT_LIGHT_OVERLAP")
+        monkeypatch.delenv("RT_CLS_STREAMS")  # (default: on its side stream; class kernels alternate between two streams)
         r1, n1, s1 = gpu_ctx.render(gs, sc.camera, cfg)
         assert np.array_equal(r0, r1) and np.array_equal(n0, n1)
         assert (s0.paths, s0.rays_extension, s0.rays_shadow, s0.rays_probe, s0.vertices_shaded) == \
