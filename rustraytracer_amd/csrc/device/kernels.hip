@@ -248,6 +248,14 @@ RTD void cursor_pad(const Cursor& c, uint32_t* arr, uint32_t cap) {
     for (uint32_t i = c.cur + (threadIdx.x & 63u); i < c.end; i += 64u)
         if (i < cap) arr[i] = kNullEntry;
 }
+// ---- a wave's share of a list: runs of `span` consecutive 64-entry groups, taken from a cursor until the list is used up.
+// Not a fixed span per wave: the class kernels of a bounce and the light kernel run side by side (abi.hip: run_lane), so a
+// launch's blocks are not all resident from its start -- a block that starts late must find less left, not its full share.
+// The cursor is word kGroupCursorWord of the list counter's own 128-B line (scene_dev.h: Ctl::cls_count), cleared by k_plan.
+RTD uint32_t group_span(uint32_t n_groups, uint32_t n_waves) {
+    const uint32_t s = n_groups / (n_waves * 8u);
+    return s < 1u ? 1u : (s > 32u ? 32u : s);
+}
 // statistics go to kStatShards cache lines that the host sums
 RTD DevStats* stat_shard(DevStats* stats) { return stats + (blockIdx.x & (kStatShards - 1)); }
 
@@ -315,7 +323,7 @@ __global__ void k_plan(Ctl* ctl, BatchCtl* batch, uint32_t it, uint32_t pool, un
     ctl->n_rays[z] = 0;
     ctl->head[z] = 0;
     for (int x = 0; x < 8; x++) ctl->xhead[(it + 2) & 3u][x][0] = 0;
-    for (int c = 0; c < kMaxCls; c++) ctl->cls_count[(it + 2) & 3u][c][0] = 0;
+    for (int c = 0; c < kMaxCls; c++) ctl->cls_count[(it + 2) & 3u][c][0] = ctl->cls_count[(it + 2) & 3u][c][kGroupCursorWord] = 0;
     ctl->fold_count[(it + 2) & 3u][0] = 0;
     if (want) {
         atomicAdd(&stats->paths, want);
@@ -1099,12 +1107,10 @@ __global__ __launch_bounds__(256, WAVES) void k_shade_cls(DevScene sc, PathState
     const uint32_t n = ctl->cls_count[it_abs & 3u][cls][0];
     const uint32_t n_groups = (n + 63u) / 64u;
     const uint32_t lane = threadIdx.x & 63u, n_waves = gridDim.x * (blockDim.x >> 6);
-    // (wave-uniform for the compiler too: the loop below and its cursors then live in SGPRs)
-    const uint32_t wave_g = blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // a contiguous span of the list per wave: its queue chunks then hold neighbouring paths in list (= queue) order
-    const uint32_t per_wave = (n_groups + n_waves - 1u) / n_waves;
-    const uint32_t g_first = wave_g * per_wave, g_end = g_first + per_wave < n_groups ? g_first + per_wave : n_groups;
-    if (g_first >= g_end) return;
+    if (n_groups == 0u) return;
+    // runs of consecutive groups per wave (group_span): its queue chunks then hold neighbouring paths in list (= queue) order
+    const uint32_t span = group_span(n_groups, n_waves);
+    uint32_t* const c_groups = &ctl->cls_count[it_abs & 3u][cls][kGroupCursorWord];
     const uint32_t chunk = pick_chunk(n, n_waves < n_groups ? n_waves : n_groups);
     const ListEnt* ent = lists.ent + ctl->cls_base[it_abs & 3u][cls];
     uint32_t* fold_out = lists.fold[(it_abs + 1u) & 1u];
@@ -1116,7 +1122,13 @@ __global__ __launch_bounds__(256, WAVES) void k_shade_cls(DevScene sc, PathState
     Cursor cs{0u, 0u}, cq0{0u, 0u}, cq1{0u, 0u}, cq2{0u, 0u}, cf{0u, 0u};
     uint32_t n_r1 = 0, n_r2 = 0, n_r3 = 0, n_v = 0;  // wave-uniform
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (uint32_t g = g_first; g < g_end; g++) {
+    uint32_t g = 0u, g_end = 0u;  // (one loop, so that the body exists once: the next run is taken when this one is used up)
+    for (;; g++) {
+        if (g >= g_end) {
+            g = wave_atomic_add(c_groups, span);
+            if (g >= n_groups) break;
+            g_end = g + span < n_groups ? g + span : n_groups;
+        }
         const uint32_t i = g * 64u + lane;
         ListEnt e{kNullEntry, 0u, -1, -1};
         if (i < n) e = ent[i];
@@ -1205,7 +1217,16 @@ __global__ __launch_bounds__(256, 4) void k_shade_light(DevScene sc, PathState i
     const uint32_t* fold_in = lists.fold[it_abs & 1u];
     __shared__ rt_w2 s_stage[4][kStageWave];
     rt_w2* const stage = s_stage[threadIdx.x >> 6];
-    for (uint32_t g = blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); g < n_groups; g += n_waves) {
+    if (n_groups == 0u) return;
+    const uint32_t span = group_span(n_groups, n_waves);
+    uint32_t* const c_groups = &ctl->cls_count[it_abs & 3u][0][kGroupCursorWord];
+    uint32_t g = 0u, g_end = 0u;
+    for (;; g++) {
+        if (g >= g_end) {
+            g = wave_atomic_add(c_groups, span);
+            if (g >= n_groups) break;
+            g_end = g + span < n_groups ? g + span : n_groups;
+        }
         uint32_t slot = kNullEntry;
         int32_t sh = -1, pr = -1;
         bool pending = false, fresh = false;

@@ -192,6 +192,7 @@ constexpr int kStatShards = 64;
 // ------------------------------------------------------------ kernel control blocks (kernels.hip)
 constexpr uint32_t kRing = 512;  // per-iteration counters live in a ring indexed by it % kRing
 
+constexpr int kGroupCursorWord = 16;
 struct Ctl {
     uint32_t n_active[kRing];
     uint32_t n_rays[kRing];
@@ -201,7 +202,7 @@ struct Ctl {
     // (RT_XCD_QUEUE) one queue head per XCD and iteration (ring of 4), each on its own 128-B line
     uint32_t xhead[4][8][32];
     // lengths of the class lists / the fold list of an iteration (ring of 4), each counter on its own 128-B line
-    uint32_t cls_count[4][kMaxCls][32];
+    uint32_t cls_count[4][kMaxCls][32];  // [..][0]: the length; [..][kGroupCursorWord]: the class kernel's group cursor
     uint32_t cls_base[4][kMaxCls];  // where the list of a class starts in Lists::ent (k_classify_scan)
     uint32_t fold_count[4][32];
 };
