@@ -70,19 +70,21 @@ WORKLOADS = {
 #   per shaded vertex: line 0 of the survivor's record written (128 B), its ray written to the ray arrays (48 B), the
 #     winner's scene records (72 B vertices + 72 B normals + 8 B meta + 120 B primitive or material record: SURVEY.md
 #     8d's B_shade doubled for f64 = 272 B);
-#   per vertex with pending direct-light terms (counted as max(R2, R3)): line 1 written and read back (2 x 128 B) and the
-#     shadow target / probe direction (24 B per ray).
+#   per vertex with a pending MIS probe (R3): line 1 (A, Q, K) written and read back (2 x 128 B); per vertex whose only
+#     pending term is a light sample (R2 - R3): its ready-made contribution, 24 B written and read back; and the shadow
+#     target / probe direction (24 B per ray).
 SHADE_BYTES_PER_VERTEX = 128 + 48 + 272
 CLASSIFY_BYTES_PER_RAY = 2 * 8 + 16  # queue entry + hit word read by the count and by the scatter pass, one 16-B list entry
 
 
 def shade_bytes(st):
     """The class kernels (vertices) -- the paths that end without a vertex are light_bytes()."""
-    pending = max(st.rays_shadow, st.rays_probe)
+    line1 = st.rays_probe
+    lone = max(st.rays_shadow - st.rays_probe, 0)
     hits = min(st.vertices_shaded, st.rays_extension)
     stored = max(st.rays_extension - st.paths, 0) * hits // max(st.rays_extension, 1)  # (hits that are not camera samples)
     return (16 * hits + 128 * stored + SHADE_BYTES_PER_VERTEX * st.vertices_shaded +
-            256 * pending + 24 * (st.rays_shadow + st.rays_probe))
+            256 * line1 + 48 * lone + 24 * (st.rays_shadow + st.rays_probe))
 
 
 def light_bytes(st):

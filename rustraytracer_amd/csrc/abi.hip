@@ -170,9 +170,9 @@ static void pool_layout(uint32_t cap, uint32_t n_cls, size_t& slots, size_t& qn,
     // of a launch's entries per kernel (kernels.hip: pick_chunk), summed generously
     slots = (size_t)cap + std::min<size_t>(cap / 16, (size_t)16 << 20) + 65536;
     qn = 3 * slots;
-    // per slot and pool: the 256-B record + 12 ray words + 2 result words + the camera sample's RNG state; 2 fold lists;
-    // per queue entry: 2 queues + hit words
-    bytes = slots * (2 * ((size_t)kRecBytes + 12 * 8 + 2 * 4 + 8) + 2 * sizeof(uint32_t)) + 3 * qn * sizeof(uint32_t) +
+    // per slot and pool: the 256-B record + 15 ray / light-term words + 2 result words + the camera sample's RNG state;
+    // 2 fold lists; per queue entry: 2 queues + hit words
+    bytes = slots * (2 * ((size_t)kRecBytes + 15 * 8 + 2 * 4 + 8) + 2 * sizeof(uint32_t)) + 3 * qn * sizeof(uint32_t) +
             slots * sizeof(ListEnt) + 4096;  // (the class lists share one arena: every path is in at most one of them)
     (void)n_cls;
 }
@@ -206,7 +206,8 @@ static int ensure_lane_capacity(rt_context* c, Lane& ln, uint32_t cap, uint32_t 
         PathState& st = ln.st[b];
         st.rec = p;
         p += slots * kRecBytes;
-        double** dptrs[] = {&st.ox, &st.oy, &st.oz, &st.dx, &st.dy, &st.dz, &st.spx, &st.spy, &st.spz, &st.pdx, &st.pdy, &st.pdz};
+        double** dptrs[] = {&st.ox, &st.oy, &st.oz, &st.dx, &st.dy, &st.dz, &st.spx, &st.spy, &st.spz, &st.pdx, &st.pdy, &st.pdz,
+                            &st.fax, &st.fay, &st.faz};
         for (auto dp : dptrs) {
             *dp = (double*)p;
             p += slots * 8;

@@ -780,8 +780,17 @@ struct ShadeA {
 // A path's record in registers.  rec_fetch: every lane of a wave calls it (class kernels) -- line 0 of all valid lanes'
 // records, and line 1 (the pending direct-light terms) of those whose list entry and flags say they carry any, arrive as
 // whole lines through the staging area.  rec_load: the same by the lane itself (k_tail).
-RTD bool rec_wants_line1(const RecRegs& R, bool valid, bool pending) {
+RTD bool rec_wants_fold(const RecRegs& R, bool valid, bool pending) {
     return valid && pending && ((uint32_t)(R.p[3].y >> 32) & (kHasShadow | kHasProbe)) != 0u;
+}
+RTD bool rec_wants_line1(const RecRegs& R, bool valid, bool pending) {
+    return valid && pending && ((uint32_t)(R.p[3].y >> 32) & kLine1) != 0u;
+}
+// a pending light sample alone (no kLine1): its complete contribution sits in the fa* words of the slot; it takes the place
+// of A in the registers (words kWA .. kWA+2), where shade_a adds it as it is
+RTD void rec_put_fa(RecRegs& R, D3 fa) {
+    R.p[8].x = r2w(fa.x); R.p[8].y = r2w(fa.y);
+    R.p[9].x = r2w(fa.z);
 }
 // line 0 of a camera sample that has not been shaded yet (scene_dev.h: kEntFresh): ray and RNG state where k_generate
 // left them, beta = 1, L = 0, no flags
@@ -807,6 +816,9 @@ template <bool RAY>
 RTD void rec_fetch(rt_w2* stage, const PathState& in, uint32_t slot, bool valid, bool pending, bool fresh, uint32_t fresh_g, RecRegs& R) {
     const uint32_t lane = threadIdx.x & 63u;
     const bool stored = valid && !fresh;
+    // (issued before the lines, on the list entry's word alone: in flight together with them)
+    D3 fa = black();
+    if (stored && pending) fa = ld3(in.fax, in.fay, in.faz, slot);
     if (__ballot(stored)) {
         stage_fetch(stage, in, stored ? slot : kNullEntry, 0u);
 #pragma unroll
@@ -820,6 +832,7 @@ RTD void rec_fetch(rt_w2* stage, const PathState& in, uint32_t slot, bool valid,
 #pragma unroll
         for (int k = 0; k < 5; k++) R.p[8 + k] = stage[lane * kStagePitch + k];
     }
+    if (stored && pending && !fold) rec_put_fa(R, fa);
     wave_sync_lds();  // (the area is free again)
 }
 RTD void rec_load(const PathState& in, uint32_t slot, bool pending, RecRegs& R) {
@@ -829,6 +842,8 @@ RTD void rec_load(const PathState& in, uint32_t slot, bool pending, RecRegs& R) 
     if (rec_wants_line1(R, true, pending)) {
 #pragma unroll
         for (int k = 0; k < 5; k++) R.p[8 + k] = rp[8 + k];
+    } else if (rec_wants_fold(R, true, pending)) {
+        rec_put_fa(R, ld3(in.fax, in.fay, in.faz, slot));
     }
 }
 
@@ -844,12 +859,19 @@ RTD void shade_a(const DevScene& sc, const PathState& in, const RecRegs& R, uint
     a.live = valid;
     a.L = black();
     a.o = black();
-    const bool fold = rec_wants_line1(R, valid, pending);
+    const bool fold = rec_wants_fold(R, valid, pending);
     if (a.live) {
         a.L = rec3<kWL>(R);
         a.o = rec3<kWO>(R);
         // ---- fold the previous vertex's direct lighting
-        if (fold) {
+        if (fold && !(fl & kLine1)) {
+            // only a light sample is pending, and K was finite: (A * n_lights) (*) K came ready-made (shade_b); an
+            // occluded one adds (0 * n_lights) (*) K = +0, as the general arm below would
+            const rt_light& lt = sc.lights[fl >> kLightShift];
+            const bool infinite = ((FEAT & kFeatEnv) != 0) && lt.kind == RT_LIGHT_INFINITE;
+            const bool seen = infinite ? sh < 0 : sh == (int32_t)lt.prim_index;
+            a.L = a.L + (seen ? rec3<kWA>(R) : black());
+        } else if (fold) {
             const uint32_t light_idx = fl >> kLightShift;
             const rt_light& lt = sc.lights[light_idx];
             const bool infinite = ((FEAT & kFeatEnv) != 0) && lt.kind == RT_LIGHT_INFINITE;
@@ -924,6 +946,7 @@ struct ShadeRes {
     uint64_t rng;
     uint32_t flags;
     bool emit_ext, emit_sh, emit_pr, keep;
+    bool line1;  // the pending terms go to line 1 (A, Q, K); a lone light sample with a finite K went to the fa* words
 };
 
 // Precondition: a.will_shade.  `os` = slot of `out` reserved for this vertex: its rays (origin, extension direction,
@@ -1039,8 +1062,12 @@ RTD ShadeRes shade_b(const DevScene& sc, const PathState& out, uint32_t os, cons
     r.emit_sh = has_sh;
     r.emit_pr = has_pr;
     r.keep = cont || has_sh || has_pr;
+    // (K = a.beta.  x - x == 0 for every finite x: with an infinite or NaN K the product 0 * K of an occluded sample is not 0,
+    // and the general arm of the fold, which forms it, has to run)
+    const bool k_finite = a.beta.x - a.beta.x == 0.0 && a.beta.y - a.beta.y == 0.0 && a.beta.z - a.beta.z == 0.0;
+    r.line1 = has_pr || (has_sh && !k_finite);
     r.flags = (bounces & kBounceMask) | (spec ? kSpecular : 0u) | (cont ? 0u : kFoldOnly) | (has_sh ? kHasShadow : 0u) |
-              (has_pr ? kHasProbe : 0u) | (light_num << kLightShift);
+              (has_pr ? kHasProbe : 0u) | (r.line1 ? kLine1 : 0u) | (light_num << kLightShift);
     r.d = wi;
     r.beta = beta;
     r.pa = pa;
@@ -1050,6 +1077,7 @@ RTD ShadeRes shade_b(const DevScene& sc, const PathState& out, uint32_t os, cons
     if (r.keep) {
         st3(out.ox, out.oy, out.oz, os, rec.p);
         if (cont) st3(out.dx, out.dy, out.dz, os, wi);
+        if (has_sh && !r.line1) st3(out.fax, out.fay, out.faz, os, cmul((black() + pa) * (double)sc.n_lights, a.beta));
     }
     return r;
 }
@@ -1061,7 +1089,7 @@ RTD void rec_store_direct(const PathState& out, uint32_t os, const ShadeA& a, co
     st3w<kWD>(ow, r.d);
     st_meta(ow, r.rng, a.orig, r.flags);
     st_beta_l(ow, r.beta, a.L);
-    if (r.emit_sh || r.emit_pr) {
+    if (r.line1) {
         st3w<kWA>(ow, r.pa);
         st3w<kWQ>(ow, r.pq);
         st3w<kWK>(ow, a.beta);
@@ -1158,9 +1186,9 @@ __global__ __launch_bounds__(256, WAVES) void k_shade_cls(DevScene sc, PathState
                     stage_slots(stage)[rank] = kNullEntry;
             }
             stage_flush(stage, out, cnt, 0u);
-            if (__ballot(r.emit_sh || r.emit_pr)) {
+            if (__ballot(r.line1)) {
                 if (a.will_shade) {
-                    if (r.emit_sh || r.emit_pr)
+                    if (r.line1)
                         stage_line1(stage, rank, os, r.pa, r.pq, a.beta);
                     else
                         stage_slots(stage)[rank] = kNullEntry;

@@ -129,6 +129,8 @@ struct PathState {
     double *dx, *dy, *dz;     // extension direction (likewise)
     double *spx, *spy, *spz;  // shadow ray target
     double *pdx, *pdy, *pdz;  // MIS probe direction
+    double *fax, *fay, *faz;  // a path whose only pending term is the light sample: what that term adds to L if the shadow
+                              // ray finds the light, (A * n_lights) (*) K, complete -- such a path has no line 1
     int32_t* sh_prim;         // closest prim along the shadow ray (Q13)
     int32_t* pr_prim;         // closest prim along the probe ray
     uint64_t* rng0;           // RNG state of a camera sample after its camera draws (k_generate; see kEntFresh)
@@ -141,10 +143,11 @@ constexpr uint32_t kSpecular = 1u << 8;
 constexpr uint32_t kFoldOnly = 1u << 9;
 constexpr uint32_t kHasShadow = 1u << 10;
 constexpr uint32_t kHasProbe = 1u << 11;
+constexpr uint32_t kLine1 = 1u << 12;  // the pending terms are in line 1 (A, Q, K); else only a light sample is pending: fa* words
 constexpr uint32_t kLightShift = 16;
 
 // queue entry = slot | kQPending | kind << 30; kRayNone fills the unused end of a wave's queue chunk.  kQPending (extension
-// entries): the path carries pending light terms, i.e. its shading kernel will want line 1 of the record -- the traversal
+// entries): the path carries pending light terms, i.e. its shading kernel will want its fa* words or line 1 of the record -- the traversal
 // kernel hands the bit on in the list entry (kEntPending), so that the loads of line 1 are issued with those of line 0
 constexpr uint32_t kRayExt = 0u, kRayShadow = 1u, kRayProbe = 2u, kRayNone = 3u;
 constexpr uint32_t kSlotMask = 0x1fffffffu, kQPending = 1u << 29;
