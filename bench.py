@@ -216,7 +216,7 @@ class Bench:
         if preset in ("material_hdr", "teapot_hdr"):
             kw = dict(kw, mesh_path=asset_dir(ASSETS, preset))
         self.scene = rr.Scene(preset, self.W / self.H, **kw)
-        # (the extra rows run on the headline bench's context: one pool of path state per GPU -- 225 GB at the default size)
+        # (the extra rows run on the headline bench's context: one pool of path state per GPU -- 238 GB at the default size)
         self.own_ctx = ctx is None
         self.ctx = rr.Context(local_rank) if ctx is None else ctx
         self.gs = self.ctx.upload(self.scene)
@@ -531,7 +531,7 @@ def main():
                        "rays_per_step": rays_all / args.steps, "paths_per_step": W * H * spp,
                        "parallelism": f"tiles{world}", "bvh_from_shared_cache": bool(b.info.get("build_from_cache", 0)),
                        # path-state slots kept alive per GPU (about 0.8 KB each): the library default is a whole batch, <= 2^28
-                       "paths_in_flight": args.paths_in_flight or "library default: min(batch, 2^28 paths) = 225 GB of path state at most, less when the device has less free",
+                       "paths_in_flight": args.paths_in_flight or "library default: min(batch, 2^28 paths) = 238 GB of path state at most, less when the device has less free",
                        "scene_commit_ms": b.info.get("build_ms")},
             "roofline": roofline(b, acc, stc, args.steps),
             "device_ms_per_step": acc["kernel_ms"] / args.steps,

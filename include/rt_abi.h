@@ -229,8 +229,8 @@ typedef struct rt_render_cfg {
                                    tile_rank (below); 0 = 1                    */
     uint32_t precision;       /* rt_precision                                  */
     uint32_t paths_in_flight; /* path-state slots kept alive per device (about
-                                   0.8 KB each); 0 = library default: a whole
-                                   batch, at most 2^28 (225 GB), halved until it
+                                   0.85 KB each); 0 = library default: a whole
+                                   batch, at most 2^28 (238 GB), halved until it
                                    fits and leaves 12 GB of the device's free
                                    memory to everybody else                      */
     uint32_t flags;           /* RT_RENDER_* below                             */

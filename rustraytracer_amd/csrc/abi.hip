@@ -1249,7 +1249,11 @@ static int run_lane(RenderJob& job, int lane_id) {
 
 static size_t batch_max() {  // camera samples per batch (film staging: 24 B each)
     static const size_t v = [] {
-        size_t lg = 28;  // 6.4 GB of staging: fewer pool drains per frame on the large configurations
+        // 2^30 samples = 25.8 GB of staging when a frame is that large.  A batch larger than the pool (2^28 paths) is refilled
+        // while it lasts and drains once: per C4 frame two drains instead of eight -- the iterations that end a batch run the
+        // machine on a few million paths.  2^28 / 2^29 / 2^30: C4 4896 / 4932 / 4960 Mrays/s, C5 4967 / 4952 / 5050
+        // (profiles/r04_sweep_batch.txt)
+        size_t lg = 30;
         if (const char* e = getenv("RT_BATCH_LOG2")) lg = (size_t)std::min(31, std::max(16, atoi(e)));
         return (size_t)1 << lg;
     }();
