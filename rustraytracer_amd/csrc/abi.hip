@@ -1339,8 +1339,7 @@ static int render_impl(rt_context* c, rt_scene* s, const rt_camera* cam, const r
             HIP_TRY(hipMalloc((void**)&c->lf, batch_cap * 3 * sizeof(double)));
             c->lf_capacity = batch_cap;
         }
-        // default pool: 256 Mi paths = a whole batch (0.8 KB per path: 225 GB of the 288 GB when a batch is that large; smaller
-        // batches size it down).  Fewer, fuller launches: C4 3822 / 4077 / 4105 / 4206 Mrays/s at 16 / 64 / 128 / 256 Mi,
+        // default pool: 256 Mi paths or a whole batch if that is less (0.85 KB per path: 238 GB of the 288 GB).  Fewer, fuller launches: C4 3822 / 4077 / 4105 / 4206 Mrays/s at 16 / 64 / 128 / 256 Mi,
         // C3 3910 / 4090 / 4141 / 4185 (profiles/r03_sweep_pool.txt, r03_sweep_pool_big.txt).  A default that does not leave
         // kPoolHeadroom of the device's free memory to everybody else (the next scene commit, the fast mode's leaf copies, the
         // caller's own buffers, other ranks sharing the GPU), or that fails to allocate, is halved (down to 16 Mi) instead of
