@@ -64,7 +64,7 @@ WORKLOADS = {
 }
 
 # Algorithmic bytes of the shading kernels (round-4 layout):
-#   per path entering a bounce (= extension ray, R1): its 16-B list entry; line 0 of its record (128 B) unless it is a
+#   per path entering a bounce (= extension ray, R1): its 8-B list entry; line 0 of its record (128 B) unless it is a
 #     camera sample, which has no record yet -- in the class kernel of its vertex, or in the light kernel when the ray
 #     found nothing (light_bytes);
 #   per shaded vertex: line 0 of the survivor's record written (128 B), its ray written to the ray arrays (48 B), the
@@ -74,7 +74,7 @@ WORKLOADS = {
 #     pending term is a light sample (R2 - R3): its ready-made contribution, 24 B written and read back; and the shadow
 #     target / probe direction (24 B per ray).
 SHADE_BYTES_PER_VERTEX = 128 + 48 + 272
-CLASSIFY_BYTES_PER_RAY = 2 * 8 + 16  # queue entry + hit word read by the count and by the scatter pass, one 16-B list entry
+CLASSIFY_BYTES_PER_RAY = 2 * 8 + 8  # queue entry + hit word read by the count and by the scatter pass, one 8-B list entry
 
 
 def shade_bytes(st):
@@ -83,16 +83,16 @@ def shade_bytes(st):
     lone = max(st.rays_shadow - st.rays_probe, 0)
     hits = min(st.vertices_shaded, st.rays_extension)
     stored = max(st.rays_extension - st.paths, 0) * hits // max(st.rays_extension, 1)  # (hits that are not camera samples)
-    return (16 * hits + 128 * stored + SHADE_BYTES_PER_VERTEX * st.vertices_shaded +
+    return (8 * hits + 128 * stored + SHADE_BYTES_PER_VERTEX * st.vertices_shaded +
             256 * line1 + 48 * lone + 24 * (st.rays_shadow + st.rays_probe))
 
 
 def light_bytes(st):
-    """The light kernel: per extension ray that found nothing its 16-B list entry, line 0 of its record (128 B) unless it
+    """The light kernel: per extension ray that found nothing its 8-B list entry, line 0 of its record (128 B) unless it
     is a camera sample, and the 24 B of film staging it retires into."""
     esc = max(st.rays_extension - st.vertices_shaded, 0)
     stored = max(st.rays_extension - st.paths, 0) * esc // max(st.rays_extension, 1)
-    return (16 + 24) * esc + 128 * stored
+    return (8 + 24) * esc + 128 * stored
 
 
 def pick_roofline(kernels):

@@ -316,6 +316,8 @@ __global__ void k_plan(Ctl* ctl, BatchCtl* batch, uint32_t it, uint32_t pool, un
     ctl->gen_first = (uint32_t)first;
     ctl->gen_slot = live;
     ctl->gen_q = ctl->n_rays[r];
+    ctl->gen_ring[it & 3u][0] = (uint32_t)first;
+    ctl->gen_ring[it & 3u][1] = live;
     ctl->n_active[r] = live + (uint32_t)want;
     ctl->n_rays[r] += (uint32_t)want;
     const uint32_t z = (it + 2) % kRing;
@@ -718,24 +720,17 @@ __global__ __launch_bounds__(256) void k_classify_scatter(const uint32_t* __rest
     for (int c = 0; c < kMaxCls; c++)
         at[c] = (uint32_t)c < lists.n_cls ? ctl->cls_base[it_abs & 3u][c] + offsets[(uint32_t)c * n_waves + wave_g] : 0u;
     // the camera samples k_generate appended to this queue: entries [gen_q, gen_q + gen_count), sample gen_first + k
-    const uint32_t fresh_lo = ctl->gen_q, fresh_n = ctl->gen_count, fresh_g = ctl->gen_first;
+    const uint32_t fresh_lo = ctl->gen_q, fresh_n = ctl->gen_count;
     const unsigned long long below = (1ull << lane) - 1ull;
     // four groups per round: their loads are in flight together
     for (uint32_t g0 = g_first; g0 < g_end; g0 += 4u) {
         uint32_t e4[4], hw4[4];
-        int32_t sh4[4], pr4[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t i = (g0 + u) * 64u + lane;
             const bool in = g0 + u < g_end && i < n;
             e4[u] = in ? queue[i] : kNullEntry;
             hw4[u] = in ? hitw[i] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {  // (consecutive entries are mostly consecutive slots: near-coalesced)
-            const bool pend = (e4[u] >> 30) == kRayExt && (e4[u] & kQPending);
-            sh4[u] = pend ? st.sh_prim[e4[u] & kSlotMask] : -1;
-            pr4[u] = pend ? st.pr_prim[e4[u] & kSlotMask] : -1;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -745,13 +740,12 @@ __global__ __launch_bounds__(256) void k_classify_scatter(const uint32_t* __rest
             const uint32_t qi = (g0 + u) * 64u + lane;
             const bool fresh = qi - fresh_lo < fresh_n;  // (unsigned: also false below fresh_lo)
             const uint32_t slot_word = (e & kSlotMask) | ((e & kQPending) ? kEntPending : 0u) | (fresh ? kEntFresh : 0u);
-            const int32_t w2 = fresh ? (int32_t)(fresh_g + (qi - fresh_lo)) : sh4[u];
 #pragma unroll
             for (int c = 0; c < kMaxCls; c++) {
                 const bool mine = cls == (uint32_t)c;
                 const unsigned long long m = __ballot(mine);
                 const uint32_t to = at[c] + (uint32_t)__popcll(m & below);
-                if (mine && to < lists.cap) lists.ent[to] = ListEnt{slot_word, hw, w2, pr4[u]};
+                if (mine && to < lists.cap) lists.ent[to] = ListEnt{slot_word, hw};
                 at[c] += (uint32_t)__popcll(m);
             }
         }
@@ -1141,6 +1135,7 @@ __global__ __launch_bounds__(256, WAVES) void k_shade_cls(DevScene sc, PathState
     uint32_t* const c_groups = &ctl->cls_count[it_abs & 3u][cls][kGroupCursorWord];
     const uint32_t chunk = pick_chunk(n, n_waves < n_groups ? n_waves : n_groups);
     const ListEnt* ent = lists.ent + ctl->cls_base[it_abs & 3u][cls];
+    const uint32_t gen_first = ctl->gen_ring[it_abs & 3u][0], gen_slot = ctl->gen_ring[it_abs & 3u][1];  // (camera samples: film slot)
     uint32_t* fold_out = lists.fold[(it_abs + 1u) & 1u];
     uint32_t* const c_slots = &ctl->n_active[itn];
     uint32_t* const c_rays = &ctl->n_rays[itn];
@@ -1158,16 +1153,18 @@ __global__ __launch_bounds__(256, WAVES) void k_shade_cls(DevScene sc, PathState
             g_end = g + span < n_groups ? g + span : n_groups;
         }
         const uint32_t i = g * 64u + lane;
-        ListEnt e{kNullEntry, 0u, -1, -1};
+        ListEnt e{kNullEntry, 0u};
         if (i < n) e = ent[i];
         const bool valid = e.slot != kNullEntry;
         // ---- records in
         const bool pending = valid && (e.slot & kEntPending), fresh = valid && (e.slot & kEntFresh);
+        // (the shadow / probe results of a path with pending terms: near-consecutive slots, in flight with the record)
+        const int32_t e_sh = pending ? in.sh_prim[e.slot & kSlotMask] : -1, e_pr = pending ? in.pr_prim[e.slot & kSlotMask] : -1;
         RecRegs R{};
-        rec_fetch<true>(stage, in, e.slot & kSlotMask, valid, pending, fresh, (uint32_t)e.sh, R);
+        rec_fetch<true>(stage, in, e.slot & kSlotMask, valid, pending, fresh, gen_first + ((e.slot & kSlotMask) - gen_slot), R);
         // ---- compute
         ShadeA a{};
-        shade_a<FEAT, KIND>(sc, in, R, e.slot & kSlotMask, e.hit, true, e.sh, e.pr, pending, valid, max_depth, a);
+        shade_a<FEAT, KIND>(sc, in, R, e.slot & kSlotMask, e.hit, true, e_sh, e_pr, pending, valid, max_depth, a);
         const unsigned long long m = __ballot(a.will_shade);
         const uint32_t cnt = (uint32_t)__popcll(m), rank = (uint32_t)__popcll(m & below);
         uint32_t os = 0;
@@ -1243,6 +1240,7 @@ __global__ __launch_bounds__(256, 4) void k_shade_light(DevScene sc, PathState i
     const uint32_t g0 = (n0 + 63u) / 64u, n_groups = g0 + (n1 + 63u) / 64u;
     const uint32_t lane = threadIdx.x & 63u, n_waves = gridDim.x * (blockDim.x >> 6);
     const uint32_t* fold_in = lists.fold[it_abs & 1u];
+    const uint32_t gen_first = ctl->gen_ring[it_abs & 3u][0], gen_slot = ctl->gen_ring[it_abs & 3u][1];
     __shared__ rt_w2 s_stage[4][kStageWave];
     rt_w2* const stage = s_stage[threadIdx.x >> 6];
     if (n_groups == 0u) return;
@@ -1263,10 +1261,12 @@ __global__ __launch_bounds__(256, 4) void k_shade_light(DevScene sc, PathState i
             if (i < n0) {
                 const ListEnt e = lists.ent[i];
                 slot = e.slot;
-                sh = e.sh;
-                pr = e.pr;
                 pending = slot != kNullEntry && (slot & kEntPending) != 0u;
                 fresh = slot != kNullEntry && (slot & kEntFresh) != 0u;
+                if (pending) {
+                    sh = in.sh_prim[slot & kSlotMask];
+                    pr = in.pr_prim[slot & kSlotMask];
+                }
             }
         } else {
             const uint32_t i = (g - g0) * 64u + lane;
@@ -1279,7 +1279,7 @@ __global__ __launch_bounds__(256, 4) void k_shade_light(DevScene sc, PathState i
         }
         const bool valid = slot != kNullEntry;
         RecRegs R{};
-        rec_fetch<(FEAT & kFeatEnv) != 0>(stage, in, slot & kSlotMask, valid, pending, fresh, (uint32_t)sh, R);
+        rec_fetch<(FEAT & kFeatEnv) != 0>(stage, in, slot & kSlotMask, valid, pending, fresh, gen_first + ((slot & kSlotMask) - gen_slot), R);
         ShadeA a{};
         shade_a<FEAT, kKindNone>(sc, in, R, slot & kSlotMask, 0u, false, sh, pr, pending, valid, max_depth, a);
         if (a.live) film_put(lf, a.orig, a.L);

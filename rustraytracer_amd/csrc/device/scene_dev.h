@@ -154,7 +154,7 @@ constexpr uint32_t kSlotMask = 0x1fffffffu, kQPending = 1u << 29;
 constexpr uint32_t kNullEntry = 0xffffffffu;  // unused queue / list entry
 constexpr uint32_t kEntPending = 1u << 30;    // in ListEnt::slot
 // A camera sample has no record until its first vertex is shaded: its ray is in the ray arrays, the state of its RNG in
-// rng0[], its film slot = its index in the batch, which k_classify hands on in ListEnt::sh; beta = 1, L = 0.  k_generate
+// rng0[], its film slot = its index in the batch = Ctl::gen_ring's first sample + (slot - first slot); beta = 1, L = 0.  k_generate
 // writes 60 B per sample instead of 180, and the shading kernels do not fetch 128 B that mostly say "one" and "zero"
 // (the lists keep the queue's order, so a wave's camera samples sit in nearly consecutive slots: these reads coalesce).
 constexpr uint32_t kEntFresh = 1u << 29;
@@ -174,9 +174,9 @@ struct ClsDesc {
     uint8_t variant;  // index into kFeatVariants
     uint8_t kind;     // kKind*
 };
-struct alignas(16) ListEnt {
-    uint32_t slot, hit;  // slot | kEntPending; hit word of the extension ray
-    int32_t sh, pr;      // the shadow / probe ray's result (meaningful with kEntPending)
+struct alignas(8) ListEnt {
+    uint32_t slot, hit;  // slot | kEntPending | kEntFresh; hit word of the extension ray.  (The shadow / probe results of a
+                         // path with pending terms are read at its slot by the shading kernel: 8 B per entry, not 16)
 };
 struct Lists {
     ListEnt* ent;      // one arena of `cap` entries: the lists of an iteration back to back, class c from Ctl::cls_base[..][c]
@@ -202,6 +202,9 @@ struct Ctl {
     uint32_t head[kRing];
     // written by k_plan for the k_generate that follows it
     uint32_t gen_count, gen_first, gen_slot, gen_q;
+    // {gen_first, gen_slot} of an iteration (ring of 4) for the kernels that shade its camera samples -- the light kernel
+    // of iteration i still runs when k_plan(i + 1) rewrites the four words above
+    uint32_t gen_ring[4][2];
     // (RT_XCD_QUEUE) one queue head per XCD and iteration (ring of 4), each on its own 128-B line
     uint32_t xhead[4][8][32];
     // lengths of the class lists / the fold list of an iteration (ring of 4), each counter on its own 128-B line
