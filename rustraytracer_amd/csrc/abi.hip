@@ -1147,7 +1147,7 @@ static int run_lane(RenderJob& job, int lane_id) {
                                (uint32_t)it, ln.cls_tab);
             hipLaunchKernelGGL(rtk::kernel_table().classify_scan, dim3(1), dim3(512), 0, stream, ln.cls_tab, cblocks * 4u, ln.ctl, (uint32_t)it);
             LANE_TRY(join_light());  // (the light kernel of the previous iteration still reads the lists)
-            hipLaunchKernelGGL(rtk::kernel_table().classify_scatter, dim3(cblocks), dim3(256), 0, stream, ln.queue[it & 1], ln.hitw, ln.st[it & 1],
+            hipLaunchKernelGGL(rtk::kernel_table().classify_scatter, dim3(cblocks), dim3(256), 0, stream, ln.queue[it & 1], ln.hitw,
                                ln.ctl, (uint32_t)it, ln.cls_tab, ln.lists);
         }
         hipEvent_t b2 = b;

@@ -707,7 +707,7 @@ __global__ __launch_bounds__(512) void k_classify_scan(uint32_t* counts, uint32_
     }
 }
 template <int DUMMY>
-__global__ __launch_bounds__(256) void k_classify_scatter(const uint32_t* __restrict__ queue, const uint32_t* __restrict__ hitw, PathState st,
+__global__ __launch_bounds__(256) void k_classify_scatter(const uint32_t* __restrict__ queue, const uint32_t* __restrict__ hitw,
                                                           const Ctl* ctl, uint32_t it_abs, const uint32_t* __restrict__ offsets, Lists lists) {
     const uint32_t n = ctl->n_rays[it_abs % kRing];
     const uint32_t lane = threadIdx.x & 63u, n_waves = gridDim.x * 4u;

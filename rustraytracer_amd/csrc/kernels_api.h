@@ -21,7 +21,7 @@ typedef void (*TraceKernel)(DevScene, PathState, const uint32_t*, Ctl*, uint32_t
                             const BatchCtl*, unsigned long long, uint32_t*);
 typedef void (*ClassifyCountKernel)(const uint32_t*, const uint32_t*, const Ctl*, uint32_t, uint32_t*);
 typedef void (*ClassifyScanKernel)(uint32_t*, uint32_t, Ctl*, uint32_t);
-typedef void (*ClassifyScatterKernel)(const uint32_t*, const uint32_t*, PathState, const Ctl*, uint32_t, const uint32_t*, Lists);
+typedef void (*ClassifyScatterKernel)(const uint32_t*, const uint32_t*, const Ctl*, uint32_t, const uint32_t*, Lists);
 typedef void (*GenKernel)(PathState, rt_camera, ChunkDesc, const uint32_t*, uint32_t*, const Ctl*);
 typedef void (*PlanKernel)(Ctl*, BatchCtl*, uint32_t, uint32_t, unsigned long long, DevStats*);
 typedef void (*IntersectKernel)(DevScene, const rt_ray*, uint64_t, rt_hit*);
