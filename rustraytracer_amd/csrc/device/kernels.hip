@@ -30,9 +30,6 @@
 // independent of how tiles are split over GPUs.
 #include "shading.h"
 
-#ifndef RT_ENT_PREFETCH
-#define RT_ENT_PREFETCH 0  // (experiment) class kernels ask for the next group's list entries a group ahead
-#endif
 #ifndef RT_XCD_QUEUE
 #define RT_XCD_QUEUE 1  // the ray queue in eight parts, one per XCD (k_trace); 0 = one head for all waves
 #endif
@@ -1149,10 +1146,6 @@ __global__ __launch_bounds__(256, WAVES) void k_shade_cls(DevScene sc, PathState
     uint32_t n_r1 = 0, n_r2 = 0, n_r3 = 0, n_v = 0;  // wave-uniform
     const unsigned long long below = (1ull << lane) - 1ull;
     uint32_t g = 0u, g_end = 0u;  // (one loop, so that the body exists once: the next run is taken when this one is used up)
-#if RT_ENT_PREFETCH
-    ListEnt e_next{kNullEntry, 0u};
-    bool have_next = false;  // wave-uniform
-#endif
     for (;; g++) {
         if (g >= g_end) {
             g = wave_atomic_add(c_groups, span);
@@ -1161,19 +1154,7 @@ __global__ __launch_bounds__(256, WAVES) void k_shade_cls(DevScene sc, PathState
         }
         const uint32_t i = g * 64u + lane;
         ListEnt e{kNullEntry, 0u};
-#if RT_ENT_PREFETCH
-        // the next group's entries are asked for while this group is computed (inside a run: its index is known)
-        if (have_next) {
-            e = e_next;
-        } else if (i < n) {
-            e = ent[i];
-        }
-        have_next = g + 1u < g_end;
-        e_next = ListEnt{kNullEntry, 0u};
-        if (have_next && i + 64u < n) e_next = ent[i + 64u];
-#else
         if (i < n) e = ent[i];
-#endif
         const bool valid = e.slot != kNullEntry;
         // ---- records in
         const bool pending = valid && (e.slot & kEntPending), fresh = valid && (e.slot & kEntFresh);
