@@ -212,6 +212,8 @@ static int ensure_lane_capacity(rt_context* c, Lane& ln, uint32_t cap, uint32_t 
             *dp = (double*)p;
             p += slots * 8;
         }
+        // (the kernels address these fifteen as ox + k * stride: kernels.hip, ldr / str)
+        if (st.oy - st.ox != (ptrdiff_t)slots || st.faz - st.ox != 14 * (ptrdiff_t)slots) return fail(RT_ERR_HIP, "pool layout: ray arrays not equally spaced");
         st.rng0 = (uint64_t*)p; p += slots * 8;
         st.sh_prim = (int32_t*)p; p += slots * 4;
         st.pr_prim = (int32_t*)p; p += slots * 4;

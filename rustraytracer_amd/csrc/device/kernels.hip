@@ -59,6 +59,22 @@ RTD void st3(f64_t* x, f64_t* y, f64_t* z, uint32_t i, D3 v) {
     reinterpret_cast<rt_w*>(y)[i] = r2w(v.y);
     reinterpret_cast<rt_w*>(z)[i] = r2w(v.z);
 }
+// The ray / light-term words of a pool are fifteen arrays of ONE slab, equally spaced, in the order of scene_dev.h: PathState
+// (abi.hip: ensure_lane_capacity checks it): word k of slot i is ox[k * stride + i] -- one base and one stride in SGPRs
+// instead of up to fifteen pointers per pool (the class kernels take two pools).
+constexpr int kRayO = 0, kRayD = 3, kRaySp = 6, kRayPd = 9, kRayFa = 12;
+RTD D3 ldr(const PathState& st, int k, uint32_t i) {
+    const size_t rs = (size_t)(st.oy - st.ox);
+    const rt_w* b = reinterpret_cast<const rt_w*>(st.ox) + (size_t)k * rs + i;
+    return d3(w2r(b[0]), w2r(b[rs]), w2r(b[2 * rs]));
+}
+RTD void str(const PathState& st, int k, uint32_t i, D3 v) {
+    const size_t rs = (size_t)(st.oy - st.ox);
+    rt_w* b = reinterpret_cast<rt_w*>(st.ox) + (size_t)k * rs + i;
+    b[0] = r2w(v.x);
+    b[rs] = r2w(v.y);
+    b[2 * rs] = r2w(v.z);
+}
 RTD rt_w* rec_words(const PathState& st, uint32_t slot) { return reinterpret_cast<rt_w*>(st.rec + (size_t)slot * kRecBytes); }
 // a vec3 at word W: one aligned pair and one word, whichever way round W's parity puts them
 template <int W>
@@ -347,8 +363,8 @@ __global__ __launch_bounds__(256) void k_generate(PathState st, rt_camera cam, C
     D3 o, d;
     uint64_t rng;
     camera_sample(cam, ck, pix_list, g, o, d, rng);
-    st3(st.ox, st.oy, st.oz, slot, o);
-    st3(st.dx, st.dy, st.dz, slot, d);
+    str(st, kRayO, slot, o);
+    str(st, kRayD, slot, d);
     st.rng0[slot] = rng;
     queue[ctl->gen_q + idx] = slot | (kRayExt << 30);
 }
@@ -517,17 +533,15 @@ __global__ __launch_bounds__(256, RT_TRACE_WAVES) void k_trace(DevScene sc, Path
                 // (an entry of kind kRayNone is the unused end of a shading wave's queue chunk: nothing to trace)
                 if (!has_ray && my < take && (e >> 30) != kRayNone) {
                     const uint32_t slot = e & kSlotMask, kind = e >> 30;
-                    D3 o = ld3(st.ox, st.oy, st.oz, slot);
-                    D3 d;
+                    // (the ray arrays through one base and one stride, ldr: the kernel had 8-10 SGPRs spilled, now none, and its
+                    // general instance 39 spilled VGPRs instead of 46)
+                    D3 o = ldr(st, kRayO, slot);
+                    D3 d = ldr(st, kind == kRayExt ? kRayD : (kind == kRayShadow ? kRaySp : kRayPd), slot);
                     double tmin = kSmall;
-                    if (kind == kRayExt) {
-                        d = ld3(st.dx, st.dy, st.dz, slot);
-                    } else if (kind == kRayShadow) {  // Visibility::unoccluded, hittable.rs:25-32
-                        d = ld3(st.spx, st.spy, st.spz, slot) - o;
+                    if (kind == kRayShadow) {  // Visibility::unoccluded, hittable.rs:25-32: d = target - o
+                        d = d - o;
                         o = o + d * kSmall;
                         tmin = 0.0;
-                    } else {
-                        d = ld3(st.pdx, st.pdy, st.pdz, slot);
                     }
                     trav_init(tv, sc, o, d, tmin, kInf);
                     slot_kind = e;
@@ -794,8 +808,8 @@ RTD void rec_fresh(const PathState& in, uint32_t slot, uint32_t g, RecRegs& R) {
     D3 o = black(), d = black();
     uint64_t rng = 0;
     if (RAY) {
-        o = ld3(in.ox, in.oy, in.oz, slot);
-        d = ld3(in.dx, in.dy, in.dz, slot);
+        o = ldr(in, kRayO, slot);
+        d = ldr(in, kRayD, slot);
         rng = in.rng0[slot];
     }
     R.p[0].x = r2w(o.x); R.p[0].y = r2w(o.y);
@@ -812,7 +826,7 @@ RTD void rec_fetch(rt_w2* stage, const PathState& in, uint32_t slot, bool valid,
     const bool stored = valid && !fresh;
     // (issued before the lines, on the list entry's word alone: in flight together with them)
     D3 fa = black();
-    if (stored && pending) fa = ld3(in.fax, in.fay, in.faz, slot);
+    if (stored && pending) fa = ldr(in, kRayFa, slot);
     if (__ballot(stored)) {
         stage_fetch(stage, in, stored ? slot : kNullEntry, 0u);
 #pragma unroll
@@ -837,7 +851,7 @@ RTD void rec_load(const PathState& in, uint32_t slot, bool pending, RecRegs& R) 
 #pragma unroll
         for (int k = 0; k < 5; k++) R.p[8 + k] = rp[8 + k];
     } else if (rec_wants_fold(R, true, pending)) {
-        rec_put_fa(R, ld3(in.fax, in.fay, in.faz, slot));
+        rec_put_fa(R, ldr(in, kRayFa, slot));
     }
 }
 
@@ -882,7 +896,7 @@ RTD void shade_a(const DevScene& sc, const PathState& in, const RecRegs& R, uint
                 } else if (pp >= 0) {
                     const int32_t li = sc.prims[pp].light_index;
                     if (li >= 0 && (uint32_t)li == light_idx) {
-                        const D3 pd = ld3(in.pdx, in.pdy, in.pdz, slot);
+                        const D3 pd = ldr(in, kRayPd, slot);
                         const rt_primitive& lpr = sc.prims[pp];
                         if (lpr.kind >= RT_PRIM_XY_RECT && lpr.xform_index < 0) {
                             // axis-aligned rect emitter: the record's normal faces the ray (set_front), so
@@ -1002,7 +1016,7 @@ RTD ShadeRes shade_b(const DevScene& sc, const PathState& out, uint32_t os, cons
                 has_sh = true;
                 const double weight = power_heuristic(1, light_pdf, 1, scattering_pdf);
                 pa = cmul(f, color) * (weight / light_pdf);
-                st3(out.spx, out.spy, out.spz, os, sp);
+                str(out, kRaySp, os, sp);
             }
         }
         {
@@ -1026,7 +1040,7 @@ RTD ShadeRes shade_b(const DevScene& sc, const PathState& out, uint32_t os, cons
                     // the radiance an escaped probe would see is a function of its direction only: fold it in now
                     const D3 pcol = infinite ? infinite_le(sc, lt, wi2) : ltcolor;
                     pq = is_black(pcol) ? black() : cmul(f2, pcol) * (weight / spdf);
-                    st3(out.pdx, out.pdy, out.pdz, os, wi2);
+                    str(out, kRayPd, os, wi2);
                 }
             }
         }
@@ -1069,9 +1083,9 @@ RTD ShadeRes shade_b(const DevScene& sc, const PathState& out, uint32_t os, cons
     r.rng = rng;
     // origin = hit point (spawn_ray, Q4); a fold-only path's d / beta are never read
     if (r.keep) {
-        st3(out.ox, out.oy, out.oz, os, rec.p);
-        if (cont) st3(out.dx, out.dy, out.dz, os, wi);
-        if (has_sh && !r.line1) st3(out.fax, out.fay, out.faz, os, cmul((black() + pa) * (double)sc.n_lights, a.beta));
+        str(out, kRayO, os, rec.p);
+        if (cont) str(out, kRayD, os, wi);
+        if (has_sh && !r.line1) str(out, kRayFa, os, cmul((black() + pa) * (double)sc.n_lights, a.beta));
     }
     return r;
 }
@@ -1373,17 +1387,17 @@ __global__ __launch_bounds__(256) void k_tail(DevScene sc, PathState buf0, PathS
         for (uint32_t j = lane; j < n_jobs; j += 64u) {
             const uint32_t job = s_job[wave][j];
             const uint32_t js = job & kSlotMask, kind = job >> 30;
-            const D3 o = ld3(in.ox, in.oy, in.oz, js);
+            const D3 o = ldr(in, kRayO, js);
             double t;
             uint32_t hs = 0;
             int32_t prim;
             if (kind == kRayShadow) {  // Visibility::unoccluded, hittable.rs:25-32
-                const D3 d = ld3(in.spx, in.spy, in.spz, js) - o;
+                const D3 d = ldr(in, kRaySp, js) - o;
                 prim = closest_hit<COUNT>(sc, o + d * kSmall, d, 0.0, kInf, t, ts, &tc);
             } else if (kind == kRayProbe) {
-                prim = closest_hit<COUNT>(sc, o, ld3(in.pdx, in.pdy, in.pdz, js), kSmall, kInf, t, ts, &tc);
+                prim = closest_hit<COUNT>(sc, o, ldr(in, kRayPd, js), kSmall, kInf, t, ts, &tc);
             } else {
-                prim = closest_hit<COUNT>(sc, o, ld3(in.dx, in.dy, in.dz, js), kSmall, kInf, t, ts, &tc, &hs);
+                prim = closest_hit<COUNT>(sc, o, ldr(in, kRayD, js), kSmall, kInf, t, ts, &tc, &hs);
             }
             s_res[wave][j] = make_int2(prim, prim < 0 ? 0 : (int)hit_word(prim, hs));
         }

@@ -125,6 +125,7 @@ struct DevScene {
 // the vertex that produced them, orig = film staging slot (sample_local * n_pixels + pixel_local).
 struct PathState {
     char* rec;
+    // (ox .. faz: fifteen arrays of one slab, equally spaced in this order -- the kernels address them as ox + k * (oy - ox))
     double *ox, *oy, *oz;     // ray origin (also in the record: the shading kernels read it there)
     double *dx, *dy, *dz;     // extension direction (likewise)
     double *spx, *spy, *spz;  // shadow ray target
