@@ -51,14 +51,6 @@ RTD double w2r(rt_w w) { return __longlong_as_double((long long)w); }
 RTD rt_w r2w(double v) { return (rt_w)__double_as_longlong(v); }
 #endif
 // the ray arrays (one f64-sized element per slot; fast mode: the low half)
-RTD D3 ld3(const f64_t* x, const f64_t* y, const f64_t* z, uint32_t i) {
-    return d3(w2r(reinterpret_cast<const rt_w*>(x)[i]), w2r(reinterpret_cast<const rt_w*>(y)[i]), w2r(reinterpret_cast<const rt_w*>(z)[i]));
-}
-RTD void st3(f64_t* x, f64_t* y, f64_t* z, uint32_t i, D3 v) {
-    reinterpret_cast<rt_w*>(x)[i] = r2w(v.x);
-    reinterpret_cast<rt_w*>(y)[i] = r2w(v.y);
-    reinterpret_cast<rt_w*>(z)[i] = r2w(v.z);
-}
 // The ray / light-term words of a pool are fifteen arrays of ONE slab, equally spaced, in the order of scene_dev.h: PathState
 // (abi.hip: ensure_lane_capacity checks it): word k of slot i is ox[k * stride + i] -- one base and one stride in SGPRs
 // instead of up to fifteen pointers per pool (the class kernels take two pools).
