@@ -8,15 +8,19 @@
 //            wave) and run the closest-hit traversal for the three root call sites
 //            of SURVEY.md 3.2: R1 extension (integrator.rs:388), R2 shadow
 //            (hittable.rs:25-39, Q13: closest hit, compared by prim index), R3 MIS
-//            probe (integrator.rs:615).  A finished extension ray is appended to the LIST OF ITS
-//            VERTEX CLASS (scene_dev.h: escaped / mesh hit or sphere-rect hit of a material group).
+//            probe (integrator.rs:615).  A finished extension ray leaves its hit word (primitive + the VERTEX CLASS
+//            of that primitive, scene_dev.h) at its queue position.
+//   k_classify_count / _scan / _scatter  a counting sort of the queue by vertex class (escaped / mesh hit or sphere-rect
+//            hit of a material group): one list of 8-B entries per class, in queue order, no atomics.
 //   k_shade_light + one k_shade_cls per class  one lane per path of the class: folds the previous
 //            vertex's direct-light terms using the R2/R3 results, rebuilds the winning hit's record,
 //            applies the emitted-light rule, builds the BSDF, samples one light + MIS
 //            (integrator.rs:530-659), samples the continuation, Russian roulette
 //            (integrator.rs:375-445), and writes survivors and their rays to the next pool / queue.
 //            Every wave of a class kernel runs ONE class over the whole launch (round 4; rounds 1-3 dealt
-//            a block's 256 consecutive slots to its waves by class).
+//            a block's 256 consecutive slots to its waves by class).  The host (abi.hip: run_lane) runs the class
+//            kernels of a bounce two at a time on two streams and the light kernel on a third, beside them and the
+//            next k_trace launch; waves take runs of 64-path groups from a cursor per list.
 // Path state (scene_dev.h): ray arrays for the traversal kernel + one 256-B record per slot for the shading kernels, two
 // pools that ping-pong per bounce: a class kernel reads record `slot` of X[it&1] and writes the survivor to a freshly
 // allocated slot of X[(it+1)&1].  Records move as whole 128-B lines, eight lanes per line, through LDS.
