@@ -33,6 +33,21 @@ def _gpu_count():
 
 
 @pytest.mark.gpu
+def test_rccl_comes_up_with_one_rank():
+    """What a one-GPU box can say about the RCCL side of bench.py --gpus N: the nccl backend of this image initialises a
+    communicator on the GPU, an all_reduce on device tensors runs through it, and the rank script ends cleanly (one rank:
+    FilmGather has nothing to exchange).  The 2 / 4 / 8-rank versions below need that many GPUs."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+           "--master-addr", "127.0.0.1", "--master-port", "29689",
+           os.path.join(ROOT, "tools", "mp_film_check.py"), "--backend", "nccl"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["ranks"] == 1 and rec["backend"] == "nccl" and rec["bit_identical"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ranks", [2, 4, 8])
 def test_ranks_on_distinct_gpus_gather_over_rccl(ranks):
     """Arms itself on a multi-GPU box: one fresh process per GPU, backend nccl (= RCCL over xGMI), FilmGather on device
